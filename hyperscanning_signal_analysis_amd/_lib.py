@@ -1,0 +1,73 @@
+"""ctypes binding of libhypermvar.so (the C ABI declared in include/hypermvar.h).
+
+The shared library is built in-tree by `__graft_entry__.build()` / `make -C csrc`.  There is NO CPU
+fallback: if the library is missing or a symbol is absent, importing the engine fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhypermvar.so")
+
+# name -> (restype, argtypes); mirrors include/hypermvar.h one to one
+SIGNATURES = {
+    "hmv_version": (c_int, []),
+    "hmv_last_error": (c_char_p, []),
+    "hmv_pad": (c_int, [c_int]),
+    "hmv_yw_workspace_doubles": (c_int64, [c_int, c_int]),
+    "hmv_lagcov_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                               c_void_p, c_void_p]),
+    "hmv_yw_solve_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "hmv_twiddles_f64": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p]),
+    "hmv_tf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_double, c_void_p]),
+    "hmv_ffdtf_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                   c_void_p]),
+    "hmv_transpose_c128": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "hmv_spectra_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "hmv_sliding_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "hmv_sliding_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                      c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
+}
+
+_lib = None
+
+
+class HypermvarLibraryError(ImportError):
+    pass
+
+
+def load():
+    """Load libhypermvar.so and bind every symbol of include/hypermvar.h.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HypermvarLibraryError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            f"(python -c 'import __graft_entry__ as g; g.build()' or make -C {_HERE}/csrc). "
+            "There is no CPU fallback for the MVAR/ffDTF path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise HypermvarLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    lib = load()
+    if rc < 0:
+        raise ValueError(f"{what}: {lib.hmv_last_error().decode()} (code {rc})")
+    raise RuntimeError(f"{what}: HIP error {rc}")

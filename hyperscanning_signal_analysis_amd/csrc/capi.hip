@@ -1,0 +1,175 @@
+// C ABI of libhypermvar.so -- argument checking and launch sequencing only; see include/hypermvar.h.
+#include "../../include/hypermvar.h"
+#include "hmv_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+int pad_of(int m) { return (m < 1 || m > HMV_MAX_CHANNELS) ? -1 : ((m + 15) / 16) * 16; }
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+}  // namespace
+
+extern "C" {
+
+int hmv_version(void) { return HMV_VERSION; }
+const char* hmv_last_error(void) { return g_err; }
+int hmv_pad(int m) { return pad_of(m); }
+
+int64_t hmv_yw_workspace_doubles(int m, int p) {
+  const int mp = pad_of(m);
+  if (mp < 0 || p < 1 || p > HMV_MAX_ORDER) return -1;
+  return hmv::yw_ws_tiles(p) * (int64_t)mp * mp;
+}
+
+int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                   const int64_t* item_start, int64_t n_items, int m, int n, int p, double* R, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_lagcov_f64: channel count must be in 1..64");
+  if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_lagcov_f64: model order must be in 1..32");
+  if (n <= p) return fail(-3, "hmv_lagcov_f64: window shorter than the model order");
+  if (!x || !item_rec || !item_start || !R || n_items < 0) return fail(-4, "hmv_lagcov_f64: null pointer");
+  hmv::LagcovArgs a;
+  a.x = x; a.rec_stride = rec_stride; a.ld = ld;
+  a.item_rec = reinterpret_cast<const long long*>(item_rec);
+  a.item_start = reinterpret_cast<const long long*>(item_start);
+  a.n_items = n_items; a.m = m; a.n = n; a.p = p; a.R = R;
+  return hmv::launch_lagcov(a, mp, S(stream));
+}
+
+int hmv_yw_solve_f64(const double* R, int64_t n_items, int m, int p, double* ws, double* ar, double* V,
+                     double* vq_logdet, int32_t* info, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_yw_solve_f64: channel count must be in 1..64");
+  if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_yw_solve_f64: model order must be in 1..32");
+  if (!R || !ws || !ar || !V || !info || n_items < 0) return fail(-4, "hmv_yw_solve_f64: null pointer");
+  hmv::YwArgs a;
+  a.R = R; a.n_items = n_items; a.m = m; a.p = p; a.ws = ws; a.ar = ar; a.V = V;
+  a.Vq_logdet = vq_logdet; a.info = info;
+  return hmv::launch_yw(a, mp, S(stream));
+}
+
+int hmv_twiddles_f64(const double* freqs, int F, double fs, int p, double* tw, void* stream) {
+  if (!freqs || !tw || F < 0 || p < 1) return fail(-4, "hmv_twiddles_f64: bad argument");
+  if (F == 0) return 0;
+  return hmv::launch_twiddles(freqs, F, fs, p, tw, S(stream));
+}
+
+int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* P,
+               double* rowsum, double* H, double* A, int32_t* info, double pivot_tau, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_tf_f64: channel count must be in 1..64");
+  if (p < 1) return fail(-2, "hmv_tf_f64: model order must be >= 1");
+  if (!ar || !tw || !info || n_items < 0 || F < 0) return fail(-4, "hmv_tf_f64: null pointer");
+  if ((P == nullptr) != (rowsum == nullptr)) return fail(-5, "hmv_tf_f64: P and rowsum go together");
+  if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_f64: pivot_tau must be in (0, 1]");
+  hmv::TfArgs a;
+  a.ar = ar; a.tw = tw; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
+  a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
+  return hmv::launch_tf_inv(a, mp, S(stream));
+}
+
+int hmv_ffdtf_norm_f64(const double* P, const double* rowsum, double* den, double* out, int64_t n_items,
+                       int F, int m, int normalise, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_ffdtf_norm_f64: channel count must be in 1..64");
+  if (!P || !out || (normalise && (!rowsum || !den))) return fail(-4, "hmv_ffdtf_norm_f64: null pointer");
+  hmv::NormArgs a;
+  a.P = P; a.rowsum = rowsum; a.den = den; a.out = out; a.n_items = n_items; a.F = F; a.m = m; a.m_pad = mp;
+  a.normalise = normalise;
+  return hmv::launch_ffdtf_norm(a, S(stream));
+}
+
+int hmv_transpose_c128(const double* in, double* out, int64_t n_items, int F, int m, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_transpose_c128: channel count must be in 1..64");
+  if (!in || !out) return fail(-4, "hmv_transpose_c128: null pointer");
+  return hmv::launch_transpose_c128(in, out, n_items, F, m, mp, S(stream));
+}
+
+int hmv_spectra_f64(const double* H, const double* V, double* Sout, int64_t n_items, int m, int F, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_spectra_f64: channel count must be in 1..64");
+  if (!H || !V || !Sout) return fail(-4, "hmv_spectra_f64: null pointer");
+  hmv::SpecArgs a;
+  a.H = H; a.V = V; a.S = Sout; a.n_items = n_items; a.F = F;
+  return hmv::launch_spectra(a, mp, S(stream));
+}
+
+// ---- fused sliding-window path ----------------------------------------------------------------------
+namespace {
+struct SlidingWs {
+  size_t off_R, off_ws, off_ar, off_V, off_P, off_rowsum, off_den, off_tw, total;
+};
+SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
+  SlidingWs w;
+  size_t o = 0;
+  const size_t t = (size_t)mp * mp;
+  w.off_R = o;      o += align256(sizeof(double) * chunk * (p + 1) * t);
+  w.off_ws = o;     o += align256(sizeof(double) * chunk * hmv::yw_ws_tiles(p) * t);
+  w.off_ar = o;     o += align256(sizeof(double) * chunk * t * p);
+  w.off_V = o;      o += align256(sizeof(double) * chunk * t);
+  w.off_P = o;      o += align256(sizeof(double) * chunk * F * t);
+  w.off_rowsum = o; o += align256(sizeof(double) * chunk * F * mp);
+  w.off_den = o;    o += align256(sizeof(double) * chunk * mp);
+  w.off_tw = o;     o += align256(sizeof(double) * F * p * 2);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F) {
+  const int mp = pad_of(m);
+  if (mp < 0 || chunk < 1 || p < 1 || p > HMV_MAX_ORDER || F < 1) return -1;
+  return (int64_t)sliding_layout(chunk, mp, p, F).total;
+}
+
+int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                          const int64_t* item_start, int64_t n_items, int m, int n, int p,
+                          const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
+                          int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
+                          int64_t chunk, double pivot_tau, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
+  if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
+  if (n <= p) return fail(-3, "hmv_sliding_ffdtf_f64: window shorter than the model order");
+  if (!x || !item_rec || !item_start || !freqs || !ffdtf || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
+    return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
+  const SlidingWs w = sliding_layout(chunk, mp, p, F);
+  if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
+  char* base = static_cast<char*>(workspace);
+  double* R = reinterpret_cast<double*>(base + w.off_R);
+  double* ws = reinterpret_cast<double*>(base + w.off_ws);
+  double* ar = reinterpret_cast<double*>(base + w.off_ar);
+  double* V = reinterpret_cast<double*>(base + w.off_V);
+  double* P = reinterpret_cast<double*>(base + w.off_P);
+  double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+  double* den = reinterpret_cast<double*>(base + w.off_den);
+  double* tw = reinterpret_cast<double*>(base + w.off_tw);
+  int rc = hmv_twiddles_f64(freqs, F, fs, p, tw, stream);
+  if (rc) return rc;
+  const size_t t = (size_t)mp * mp;
+  for (int64_t i0 = 0; i0 < n_items; i0 += chunk) {
+    const int64_t c = (n_items - i0 < chunk) ? (n_items - i0) : chunk;
+    double* ar_c = ar_out ? ar_out + (size_t)i0 * t * p : ar;
+    double* V_c = V_out ? V_out + (size_t)i0 * t : V;
+    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, stream);
+    if (rc) return rc;
+    rc = hmv_yw_solve_f64(R, c, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, stream);
+    if (rc) return rc;
+    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, stream);
+    if (rc) return rc;
+    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

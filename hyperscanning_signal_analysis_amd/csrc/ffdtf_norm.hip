@@ -1,0 +1,101 @@
+// K4 -- full-frequency normalisation + layout change to the reference's (m, m, F) arrays.
+//
+// Replaces the m^2-iteration Python loop of `full_freq_dtf` (/root/reference/src/mtmvar.py:281-283):
+//     ff[i, j, f] = dtf[i, j, f] / sum_{j', f'} dtf[i, j', f'].
+// K3 leaves P[item][f][i][j] = |H_ij(f)|^2 (kernel-natural layout, j contiguous) and the per-(f, i)
+// partial sums rowsum[item][f][i].  Here:
+//   den_kernel      den[item][i] = sum_f rowsum[item][f][i]   (fixed f order: bit-reproducible)
+//   norm_kernel     out[item][i][j][f] = P[item][f][i][j] / den[item][i]  via a 64(f) x 64(j) LDS tile so
+//                   that both the global reads (j contiguous) and the writes (f contiguous) are full
+//                   512-byte runs.  HBM-bound: 2 x 8 B per output element.
+// `normalise == 0` gives the plain |H|^2 of `dtf_multivariate` (mtmvar.py:232).
+#include "hmv_common.h"
+#include "hmv_kernels.h"
+
+namespace hmv {
+
+__global__ void __launch_bounds__(64) den_kernel(const double* rowsum, double* den, int F, int m_pad) {
+  const long long item = blockIdx.x;
+  const int i = threadIdx.x;
+  if (i >= m_pad) return;
+  const double* rs = rowsum + (size_t)item * F * m_pad + i;
+  double acc = 0.0;
+  for (int f = 0; f < F; ++f) acc += rs[(size_t)f * m_pad];
+  den[(size_t)item * m_pad + i] = acc;
+}
+
+// grid: (ceil(F/64) * n_items, m); block 256
+__global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
+  __shared__ double tile[64][65];
+  const int MP = a.m_pad, m = a.m, F = a.F;
+  const int nft = (F + 63) / 64;
+  const long long item = blockIdx.x / nft;
+  const int f0 = (blockIdx.x % nft) * 64;
+  const int i = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const double* P = a.P + ((size_t)item * F * MP + (size_t)i) * MP;   // + f*MP*MP + j
+  // read: rows f, columns j (contiguous)
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int f = f0 + r;
+    double v = 0.0;
+    if (f < F && tx < m) v = P[(size_t)f * MP * MP + tx];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  double scale_den = 1.0;
+  if (a.normalise) scale_den = a.den[(size_t)item * MP + i];
+  double* out = a.out + (((size_t)item * m + i) * m) * F;             // + j*F + f
+#pragma unroll 4
+  for (int r = ty; r < 64; r += 4) {
+    const int j = r;
+    const int f = f0 + tx;
+    if (j < m && f < F) {
+      const double v = tile[tx][j];
+      out[(size_t)j * F + f] = a.normalise ? v / scale_den : v;
+    }
+  }
+}
+
+// complex [n_items][F][MP][MP] -> [n_items][m][m][F]; grid (ceil(F/32) * n_items, m), block 256
+__global__ void __launch_bounds__(256) transpose_c128_kernel(const double2* in, double2* out, int F, int m, int MP) {
+  __shared__ double2 tile[32][65];
+  const int nft = (F + 31) / 32;
+  const long long item = blockIdx.x / nft;
+  const int f0 = (blockIdx.x % nft) * 32;
+  const int i = blockIdx.y;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const double2* src = in + ((size_t)item * F * MP + (size_t)i) * MP;
+  for (int r = ty; r < 32; r += 4) {
+    const int f = f0 + r;
+    double2 v = make_double2(0.0, 0.0);
+    if (f < F && tx < m) v = src[(size_t)f * MP * MP + tx];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  double2* dst = out + (((size_t)item * m + i) * m) * F;
+  const int fx = threadIdx.x & 31, jy = threadIdx.x >> 5;   // 32 f x 8 j per pass
+  for (int j = jy; j < 64; j += 8) {
+    const int f = f0 + fx;
+    if (j < m && f < F) dst[(size_t)j * F + f] = tile[fx][j];
+  }
+}
+
+int launch_ffdtf_norm(const NormArgs& a, hipStream_t st) {
+  if (a.n_items == 0) return 0;
+  if (a.normalise)
+    hipLaunchKernelGGL(den_kernel, dim3((unsigned)a.n_items), dim3(64), 0, st, a.rowsum, a.den, a.F, a.m_pad);
+  const dim3 grid((unsigned)(((a.F + 63) / 64) * a.n_items), a.m);
+  hipLaunchKernelGGL(norm_kernel, grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int launch_transpose_c128(const double* in, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st) {
+  if (n_items == 0) return 0;
+  const dim3 grid((unsigned)(((F + 31) / 32) * n_items), m);
+  hipLaunchKernelGGL(transpose_c128_kernel, grid, dim3(256), 0, st, reinterpret_cast<const double2*>(in),
+                     reinterpret_cast<double2*>(out), F, m, m_pad);
+  return (int)hipGetLastError();
+}
+
+}  // namespace hmv

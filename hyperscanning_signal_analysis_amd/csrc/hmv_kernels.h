@@ -1,0 +1,76 @@
+// Internal launch interface between the C-ABI (capi.hip) and the kernels.  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hmv {
+
+// ---- K1 lag covariance ------------------------------------------------------------------------
+struct LagcovArgs {
+  const double* x;          // [n_rec][m][ld]  (channel-major, sample-contiguous)
+  long long rec_stride;     // doubles between recordings
+  long long ld;             // doubles between channels
+  const long long* item_rec;    // [n_items] recording index of each window (device)
+  const long long* item_start;  // [n_items] first sample of each window (device)
+  long long n_items;
+  int m, n, p;              // channels, window length, model order
+  double* R;                // [n_items][p+1][MP][MP]
+};
+int launch_lagcov(const LagcovArgs& a, int m_pad, hipStream_t st);
+
+// ---- K2 Yule-Walker solve (block LDL^T of the block-Toeplitz normal equations) ------------------
+struct YwArgs {
+  const double* R;          // [n_items][p+1][MP][MP]
+  long long n_items;
+  int m, p;
+  double* ws;               // [n_items][ws_tiles(p)][MP][MP] scratch
+  double* ar;               // [n_items][MP][MP][p]   (row, col, lag) -- lag fastest
+  double* V;                // [n_items][MP][MP]
+  double* Vq_logdet;        // optional [n_items][p]: log det V_q for q = 1..p (model-order criterion)
+  int* info;                // [n_items]
+};
+long long yw_ws_tiles(int p);
+int launch_yw(const YwArgs& a, int m_pad, hipStream_t st);
+
+// ---- K3 transfer matrix inverse ---------------------------------------------------------------
+struct TfArgs {
+  const double* ar;         // [n_items][MP][MP][p]
+  const double* tw;         // [F][p][2]
+  double* P;                // optional [n_items][F][MP][MP]
+  double* rowsum;           // required with P: [n_items][F][MP]
+  double* H;                // optional complex [n_items][F][MP][MP]
+  double* A;                // optional complex [n_items][F][MP][MP]
+  int* info;                // [n_items*F]
+  long long n_items;
+  int F, p, m;
+  double tau;               // pivot threshold: 1.0 = LAPACK partial pivoting
+};
+int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
+int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);
+
+// ---- K4 ffDTF normalisation + layout transposes -------------------------------------------------
+struct NormArgs {
+  const double* P;          // [n_items][F][MP][MP]
+  const double* rowsum;     // [n_items][F][MP]
+  double* den;              // [n_items][MP] scratch/out: sum_f rowsum
+  double* out;              // [n_items][m][m][F]
+  long long n_items;
+  int F, m, m_pad;
+  int normalise;            // 1: ffDTF, 0: plain |H|^2 (dtf_multivariate)
+};
+int launch_ffdtf_norm(const NormArgs& a, hipStream_t st);
+
+// complex [n_items][F][MP][MP] -> complex [n_items][m][m][F]
+int launch_transpose_c128(const double* in, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
+
+// ---- K5 spectra S(f) = H V H^T (plain transpose) ---------------------------------------------------
+struct SpecArgs {
+  const double* H;          // complex [n_items][F][MP][MP]
+  const double* V;          // [n_items][MP][MP]
+  double* S;                // complex [n_items][F][MP][MP]
+  long long n_items;
+  int F;
+};
+int launch_spectra(const SpecArgs& a, int m_pad, hipStream_t st);
+
+}  // namespace hmv

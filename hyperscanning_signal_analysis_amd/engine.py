@@ -1,0 +1,202 @@
+"""Device-side engine: stages buffers with PyTorch-ROCm and drives the HIP kernels through the C ABI.
+
+PyTorch is plumbing here (device memory, streams, H2D/D2H copies); all arithmetic of the hot path
+runs in libhypermvar.so.  Every method takes / returns torch tensors that live on the engine's device;
+`hyperscanning_signal_analysis_amd.mtmvar` wraps them into the reference's NumPy signatures.
+
+Layouts ("MP layout": channels padded to MP = 16*ceil(m/16)):
+    R       (items, p+1, MP, MP)      lag covariances                               K1
+    ar      (items, MP, MP, p)        AR coefficients, lag fastest                  K2
+    V       (items, MP, MP)           residual covariance                           K2
+    P/H/A/S (items, F, MP, MP)        kernel-natural per-frequency matrices         K3 / K5
+    ffdtf   (items, m, m, F)          the reference's (m, m, F) array per window    K4
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["Engine", "default_engine", "SingularMatrixError"]
+
+
+class SingularMatrixError(np.linalg.LinAlgError):
+    """Raised where the reference's np.linalg.solve / np.linalg.inv raise LinAlgError('Singular matrix')."""
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Engine:
+    def __init__(self, device=None, pivot_tau: float = 1.0, max_workspace_bytes: int = 24 << 30):
+        self.lib = _lib.load()                      # fails loudly when the HIP library is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("hypermvar needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.pivot_tau = float(pivot_tau)
+        self.max_workspace_bytes = int(max_workspace_bytes)
+        self._ws = None
+
+    # ------------------------------------------------------------------ helpers
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_device(self, a, dtype=torch.float64):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def pad(self, m: int) -> int:
+        mp = self.lib.hmv_pad(int(m))
+        if mp < 0:
+            raise ValueError(f"hypermvar supports 1..64 channels, got {m}")
+        return mp
+
+    def _workspace(self, nbytes: int):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    @staticmethod
+    def raise_on_info(info: torch.Tensor, what: str):
+        if bool((info != 0).any().item()):
+            raise SingularMatrixError("Singular matrix")
+
+    # ------------------------------------------------------------------ K1
+    def lagcov(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int):
+        """x: (n_rec, m, T) float64 device tensor -> R (items, p+1, MP, MP)."""
+        assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
+        x = x if x.stride(2) == 1 else x.contiguous()
+        n_rec, m, T = x.shape
+        mp = self.pad(m)
+        n_items = int(item_rec.numel())
+        R = self.empty(n_items, p + 1, mp, mp)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_lagcov_f64(x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(),
+                                         item_start.data_ptr(), n_items, m, int(n), int(p), R.data_ptr(),
+                                         self.stream())
+        _lib.check(rc, "hmv_lagcov_f64")
+        return R
+
+    # ------------------------------------------------------------------ K2
+    def yw_solve(self, R: torch.Tensor, m: int, want_logdet: bool = False):
+        n_items, p1, mp, _ = R.shape
+        p = p1 - 1
+        ws = self.empty(n_items * int(self.lib.hmv_yw_workspace_doubles(m, p)))
+        ar = self.empty(n_items, mp, mp, p)
+        V = self.empty(n_items, mp, mp)
+        info = self.empty(n_items, dtype=torch.int32)
+        logdet = self.empty(n_items, p) if want_logdet else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_yw_solve_f64(R.data_ptr(), n_items, m, p, ws.data_ptr(), ar.data_ptr(), V.data_ptr(),
+                                           _ptr(logdet), info.data_ptr(), self.stream())
+        _lib.check(rc, "hmv_yw_solve_f64")
+        return ar, V, logdet, info
+
+    # ------------------------------------------------------------------ K3 (+K4/K5 layout kernels)
+    def twiddles(self, freqs, fs: float, p: int):
+        f = self.to_device(np.asarray(freqs, dtype=np.float64))
+        tw = self.empty(f.numel(), p, 2)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_twiddles_f64(f.data_ptr(), f.numel(), float(fs), p, tw.data_ptr(), self.stream())
+        _lib.check(rc, "hmv_twiddles_f64")
+        return tw
+
+    def transfer(self, ar: torch.Tensor, m: int, tw: torch.Tensor, want_P=True, want_H=False, want_A=False):
+        """ar (items, MP, MP, p) -> dict of kernel-natural (items, F, MP, MP) tensors + info."""
+        n_items, mp, _, p = ar.shape
+        F = tw.shape[0]
+        out = {}
+        P = self.empty(n_items, F, mp, mp) if want_P else None
+        rowsum = self.empty(n_items, F, mp) if want_P else None
+        H = self.empty(n_items, F, mp, mp, 2) if want_H else None
+        A = self.empty(n_items, F, mp, mp, 2) if want_A else None
+        info = self.empty(n_items * F, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_tf_f64(ar.data_ptr(), n_items, m, p, tw.data_ptr(), F, _ptr(P), _ptr(rowsum),
+                                     _ptr(H), _ptr(A), info.data_ptr(), self.pivot_tau, self.stream())
+        _lib.check(rc, "hmv_tf_f64")
+        out.update(P=P, rowsum=rowsum, H=H, A=A, info=info)
+        return out
+
+    def normalise(self, P, rowsum, m: int, normalise: bool = True):
+        n_items, F, mp, _ = P.shape
+        den = self.empty(n_items, mp)
+        out = self.empty(n_items, m, m, F)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_ffdtf_norm_f64(P.data_ptr(), _ptr(rowsum), den.data_ptr(), out.data_ptr(), n_items,
+                                             F, m, 1 if normalise else 0, self.stream())
+        _lib.check(rc, "hmv_ffdtf_norm_f64")
+        return out, den
+
+    def to_mmf_complex(self, Z: torch.Tensor, m: int):
+        """(items, F, MP, MP, 2) -> complex128 (items, m, m, F), the reference's H / A / spectra layout."""
+        n_items, F, mp, _, _ = Z.shape
+        out = self.empty(n_items, m, m, F, 2)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_transpose_c128(Z.data_ptr(), out.data_ptr(), n_items, F, m, self.stream())
+        _lib.check(rc, "hmv_transpose_c128")
+        return torch.view_as_complex(out)
+
+    def spectra(self, H: torch.Tensor, V: torch.Tensor, m: int):
+        n_items, F, mp, _, _ = H.shape
+        S = self.empty(n_items, F, mp, mp, 2)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_spectra_f64(H.data_ptr(), V.data_ptr(), S.data_ptr(), n_items, m, F, self.stream())
+        _lib.check(rc, "hmv_spectra_f64")
+        return S
+
+    # ------------------------------------------------------------------ fused sliding-window path
+    def sliding_chunk(self, n_items: int, m: int, p: int, F: int) -> int:
+        per_item = int(self.lib.hmv_sliding_workspace_bytes(1, m, p, F))
+        return max(1, min(n_items, self.max_workspace_bytes // max(per_item, 1)))
+
+    def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
+                      freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
+                      check: bool = True, chunk: int | None = None):
+        """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4)."""
+        assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
+        x = x if x.stride(2) == 1 else x.contiguous()
+        n_rec, m, T = x.shape
+        mp = self.pad(m)
+        n_items = int(item_rec.numel())
+        f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
+        F = int(f.numel())
+        chunk = self.sliding_chunk(n_items, m, p, F) if chunk is None else int(chunk)
+        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F))
+        ws = self._workspace(nbytes)
+        if out is None:
+            out = self.empty(n_items, m, m, F)
+        ar = self.empty(n_items, mp, mp, p) if return_ar else None
+        V = self.empty(n_items, mp, mp) if return_ar else None
+        info_yw = self.empty(n_items, dtype=torch.int32)
+        info_tf = self.empty(n_items * F, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_sliding_ffdtf_f64(
+                x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
+                m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
+                info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau,
+                self.stream())
+        _lib.check(rc, "hmv_sliding_ffdtf_f64")
+        if check:
+            self.raise_on_info(info_yw, "yw")
+            self.raise_on_info(info_tf, "tf")
+        if return_ar:
+            return out, ar, V, (info_yw, info_tf)
+        return out
+
+
+_default = None
+
+
+def default_engine() -> Engine:
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default

@@ -1,0 +1,202 @@
+"""Drop-in replacements for the MVAR / DTF functions of the reference's `src/mtmvar.py`.
+
+Same names, parameters, defaults, return shapes, printed messages and error behaviour as
+/root/reference/src/mtmvar.py:35-284 and :551-601; the arithmetic runs on the MI355X through
+libhypermvar.so (see `engine.py`).  NumPy arrays in, freshly allocated NumPy arrays out.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * `count_corr(..., iwhat=2)` (never used by the reference, quirk Q8) is not provided;
+  * `mvar_criterion` gets all orders 1..pmax from ONE factorisation at pmax (the block LDL^T partial
+    sums are exactly the lower-order residual covariances) instead of pmax separate fits;
+  * `multivariate_spectra` and `full_freq_dtf` share nothing in the reference (each refits the model);
+    here each call still fits once, but `mvar_analysis()` returns both from a single fit.
+Supported sizes: 1..64 channels, model order 1..32.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import Engine, SingularMatrixError, default_engine
+
+__all__ = ["count_corr", "ar_coeff", "mvar_transfer_function", "multivariate_spectra", "dtf_multivariate",
+           "full_freq_dtf", "mvar_criterion", "mvar_analysis", "lag_covariances"]
+
+
+# ----------------------------------------------------------------------------- internals
+def _as_trials(data, eng: Engine):
+    """(m, n) or (m, n, trials) ndarray -> device tensor (trials, m, n)."""
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 2:
+        data = data[:, :, None]
+    if data.ndim != 3:
+        raise ValueError("signals must have shape (channels, samples) or (channels, samples, trials)")
+    x = torch.as_tensor(np.ascontiguousarray(data.transpose(2, 0, 1))).to(eng.device)
+    return x
+
+
+def _lagcov_mean(data, p: int, eng: Engine):
+    """Trial-averaged lag covariances in MP layout: (1, p+1, MP, MP).  mtmvar.py:54-85."""
+    x = _as_trials(data, eng)
+    trials, m, n = x.shape
+    if n <= p:
+        raise ValueError(f"need more samples ({n}) than the model order ({p})")
+    rec = torch.arange(trials, dtype=torch.int64, device=eng.device)
+    start = torch.zeros(trials, dtype=torch.int64, device=eng.device)
+    R = eng.lagcov(x, rec, start, n, p)
+    if trials > 1:
+        R = R.sum(dim=0, keepdim=True) / trials          # mtmvar.py:78-85
+    return R, m, n
+
+
+def _fit(data, p: int, eng: Engine, want_logdet=False):
+    R, m, n = _lagcov_mean(data, p, eng)
+    ar, V, logdet, info = eng.yw_solve(R, m, want_logdet)
+    eng.raise_on_info(info, "ar_coeff")
+    return ar, V, logdet, m, n
+
+
+def _order(signals, max_model_order, optimal_model_order, crit_type, plot, comment, style):
+    if optimal_model_order is None:
+        _, _, optimal_model_order = mvar_criterion(signals, max_model_order, crit_type, plot)
+        if style == "spectra":
+            print('Optimal model order for all channels: p = ', str(optimal_model_order))
+        else:
+            comment_str = '' if comment is None else comment + ' '
+            print(f'Optimal model order for all {comment_str}channels: p = {optimal_model_order}')
+    else:
+        if style == "spectra":
+            print('Using provided model order: p = ', str(optimal_model_order))
+        else:
+            print(f'Using provided model order: p = {optimal_model_order}')
+    return int(optimal_model_order)
+
+
+# ----------------------------------------------------------------------------- public API
+def lag_covariances(x, p):
+    """R_l = X[:, :n-l] X[:, l:].T / n, l = 0..p, trial-averaged; (p+1, m, m).  (mtmvar.py:57-59,72-73)"""
+    eng = default_engine()
+    R, m, _ = _lagcov_mean(x, int(p), eng)
+    return R[0, :, :m, :m].cpu().numpy()
+
+
+def count_corr(x, ip, iwhat):
+    """Block-Toeplitz normal equations (mtmvar.py:35-87): returns (r_left, r_right, r)."""
+    if iwhat != 1:
+        raise NotImplementedError("only the biased estimator (iwhat=1) is implemented (the reference never uses 2)")
+    R = lag_covariances(x, ip)
+    m = R.shape[1]
+    r_left = np.zeros((m * ip, m * ip))
+    r_right = np.zeros((m * ip, m))
+    for a in range(ip):
+        r_right[a * m:(a + 1) * m] = R[a + 1]
+        for b in range(ip):
+            r_left[a * m:(a + 1) * m, b * m:(b + 1) * m] = R[a - b] if a >= b else R[b - a].T
+    return r_left, r_right, R[0].copy()
+
+
+def ar_coeff(data, model_order=5):
+    """MVAR coefficients (channels, channels, model_order) and residual covariance (mtmvar.py:90-123)."""
+    eng = default_engine()
+    ar, V, _, m, _ = _fit(data, int(model_order), eng)
+    return ar[0, :m, :m, :].cpu().numpy(), V[0, :m, :m].cpu().numpy()
+
+
+def mvar_transfer_function(ar_coeffs, freqs, fs):
+    """H(f) = inv(I - sum_k A_k exp(-2 pi i f k / fs)) and A(f); both (chan, chan, len(freqs)) complex.
+
+    mtmvar.py:126-162.  Raises numpy.linalg.LinAlgError('Singular matrix') like np.linalg.inv.
+    """
+    eng = default_engine()
+    ar_coeffs = np.asarray(ar_coeffs, dtype=np.float64)
+    m, _, p = ar_coeffs.shape
+    mp = eng.pad(m)
+    arp = torch.zeros(1, mp, mp, p, dtype=torch.float64, device=eng.device)
+    arp[0, :m, :m, :] = torch.as_tensor(ar_coeffs).to(eng.device)
+    tw = eng.twiddles(freqs, fs, p)
+    out = eng.transfer(arp, m, tw, want_P=False, want_H=True, want_A=True)
+    eng.raise_on_info(out["info"], "mvar_transfer_function")
+    H = eng.to_mmf_complex(out["H"], m)[0].cpu().numpy()
+    A = eng.to_mmf_complex(out["A"], m)[0].cpu().numpy()
+    return H, A
+
+
+def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
+    """One fit, several products: any of 'ar', 'V', 'H', 'A', 'dtf', 'ffdtf', 'spectra' as a dict.
+
+    Not in the reference (which refits for every product, mtmvar.py:165-284); this is what the pipeline
+    mirror uses so that ffDTF and spectra share the lag covariances, the solve and the inverses.
+    """
+    eng = default_engine()
+    p = int(model_order)
+    ar, V, _, m, _ = _fit(signals, p, eng)
+    tw = eng.twiddles(freqs, fs, p)
+    need_H = any(k in want for k in ("H", "spectra"))
+    need_P = any(k in want for k in ("dtf", "ffdtf"))
+    t = eng.transfer(ar, m, tw, want_P=need_P, want_H=need_H, want_A="A" in want)
+    eng.raise_on_info(t["info"], "transfer")
+    res = {}
+    if "ar" in want:
+        res["ar"] = ar[0, :m, :m, :].cpu().numpy()
+    if "V" in want:
+        res["V"] = V[0, :m, :m].cpu().numpy()
+    if "H" in want:
+        res["H"] = eng.to_mmf_complex(t["H"], m)[0].cpu().numpy()
+    if "A" in want:
+        res["A"] = eng.to_mmf_complex(t["A"], m)[0].cpu().numpy()
+    if "dtf" in want:
+        res["dtf"] = eng.normalise(t["P"], t["rowsum"], m, normalise=False)[0][0].cpu().numpy()
+    if "ffdtf" in want:
+        res["ffdtf"] = eng.normalise(t["P"], t["rowsum"], m, normalise=True)[0][0].cpu().numpy()
+    if "spectra" in want:
+        S = eng.spectra(t["H"], V, m)
+        res["spectra"] = eng.to_mmf_complex(S, m)[0].cpu().numpy()
+    return res
+
+
+def multivariate_spectra(signals, freqs, fs, max_model_order=20, optimal_model_order=None, crit_type='AIC'):
+    """S(f) = H V H.T (plain transpose, mtmvar.py:199); (N_chan, N_chan, N_f) complex128."""
+    p = _order(signals, max_model_order, optimal_model_order, crit_type, True, None, "spectra")
+    return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("spectra",))["spectra"]
+
+
+def dtf_multivariate(signals, freqs, fs, max_model_order=20, optimal_model_order=None, crit_type='AIC', comment=None):
+    """Un-normalised |H|^2 (mtmvar.py:204-234, quirk Q2); (N_chan, N_chan, N_f) float64."""
+    p = _order(signals, max_model_order, optimal_model_order, crit_type, False, comment, "dtf")
+    return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("dtf",))["dtf"]
+
+
+def full_freq_dtf(signals, freqs, fs, max_model_order=20, optimal_model_order=None, crit_type='AIC'):
+    """ffDTF_ij(f) = |H_ij(f)|^2 / sum_f sum_k |H_ik(f)|^2 (mtmvar.py:237-284)."""
+    p = _order(signals, max_model_order, optimal_model_order, crit_type, False, None, "dtf")
+    return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("ffdtf",))["ffdtf"]
+
+
+def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):
+    """AIC / HQ / SC over p = 1..max_model_order (mtmvar.py:551-601): (crit, p_range, optimal_order)."""
+    data = np.asarray(data, dtype=np.float64)
+    n_channels, n_samples = data.shape                       # 2-D only, like the reference
+    model_order_range = np.arange(1, max_model_order + 1, dtype=int)
+    if crit_type == 'AIC':
+        pen = 2 * model_order_range * n_channels ** 2 / n_samples
+    elif crit_type == 'HQ':
+        pen = 2 * np.log(np.log(n_samples)) * model_order_range * n_channels ** 2 / n_samples
+    elif crit_type == 'SC':
+        pen = np.log(n_samples) * model_order_range * n_channels ** 2 / n_samples
+    else:
+        raise ValueError("Invalid criterion type. Choose from 'AIC', 'HQ', 'SC'.")
+    eng = default_engine()
+    _, _, logdet, _, _ = _fit(data, int(max_model_order), eng, want_logdet=True)
+    crit = logdet[0].cpu().numpy() + pen
+    optimal_model_range = model_order_range[np.argmin(crit)]
+    if plot:
+        import matplotlib.pyplot as plt
+        plt.figure()
+        plt.plot(model_order_range, crit, marker='o')
+        plt.plot(optimal_model_range, np.min(crit), 'ro')
+        plt.xlabel('Model order p')
+        plt.ylabel(f'{crit_type} criterion')
+        plt.title(f'MVAR Model Order Selection ({crit_type}). The best order = {optimal_model_range}')
+        plt.grid(True)
+        plt.show()
+    return crit, model_order_range, optimal_model_range

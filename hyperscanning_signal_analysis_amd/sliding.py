@@ -1,0 +1,82 @@
+"""Batched sliding-window ffDTF: the (dyad x window) batch dimension the GPU path is built around.
+
+`window_positions` / `create_windows` follow `EEG_IBI_FFDTF_Pipeline._create_windows`
+(/root/reference/src/eeg_alpha_ibi_ffdtf.py:451-518) -- same start positions, same ValueErrors.
+`sliding_ffdtf` is the batched equivalent of calling `full_freq_dtf(window, freqs, fs,
+optimal_model_order=p)` (/root/reference/src/mtmvar.py:237-284) on every window of every recording.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .engine import Engine, default_engine
+
+__all__ = ["window_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf_device", "window_items"]
+
+
+def window_positions(T: int, n_windows: int = 3, window_size=None):
+    """Start positions and window length of `_create_windows` (eeg_alpha_ibi_ffdtf.py:451-518)."""
+    if window_size is None:
+        if T % n_windows != 0:
+            raise ValueError(
+                f"Cannot evenly divide signal of length {T} into {n_windows} "
+                f"non-overlapping windows. Provide a specific window_size."
+            )
+        window_size = T // n_windows
+    else:
+        min_required_size = (T + n_windows - 1) // n_windows
+        if window_size < min_required_size:
+            raise ValueError(
+                f"window_size={window_size} is too short. To cover {T} samples "
+                f"with {n_windows} windows without leaving gaps, the minimum "
+                f"window_size is {min_required_size}."
+            )
+        if window_size > T:
+            raise ValueError(f"window_size ({window_size}) cannot exceed signal length ({T}).")
+    max_start = T - window_size
+    if max_start < n_windows - 1 and n_windows > 1:
+        raise ValueError(
+            f"window_size={window_size} is too large to generate {n_windows} "
+            f"distinct windows. Decrease window_size or n_windows."
+        )
+    if n_windows == 1:
+        positions = np.array([0], dtype=int)
+    else:
+        positions = np.linspace(0, max_start, n_windows, dtype=int)
+    return positions, int(window_size)
+
+
+def create_windows(signals, n_windows=3, window_size=None):
+    """List of `n_windows` views (channels, window_size), as the reference returns."""
+    positions, w = window_positions(signals.shape[1], n_windows, window_size)
+    return [signals[:, s:s + w] for s in positions]
+
+
+def window_items(n_rec: int, positions, device):
+    """(item_rec, item_start) int64 device tensors for `n_rec` recordings sharing the same positions."""
+    pos = torch.as_tensor(np.asarray(positions, dtype=np.int64))
+    item_start = pos.repeat(n_rec).to(device)
+    item_rec = torch.arange(n_rec, dtype=torch.int64).repeat_interleave(len(pos)).to(device)
+    return item_rec, item_start
+
+
+def sliding_ffdtf_device(x: torch.Tensor, window_size: int, n_windows: int, p: int, freqs, fs: float,
+                         engine: Engine | None = None, out: torch.Tensor | None = None, check: bool = True):
+    """x: device tensor (n_rec, m, T) -> device tensor (n_rec, n_windows, m, m, F).  No host copies."""
+    eng = engine or default_engine()
+    n_rec, m, T = x.shape
+    positions, w = window_positions(T, n_windows, window_size)
+    item_rec, item_start = window_items(n_rec, positions, eng.device)
+    ff = eng.sliding_ffdtf(x, item_rec, item_start, w, p, freqs, fs, out=out, check=check)
+    return ff.view(n_rec, len(positions), m, m, -1)
+
+
+def sliding_ffdtf(x, window_size, n_windows, p, freqs, fs, engine: Engine | None = None):
+    """NumPy in / NumPy out.  x: (m, T) or (n_rec, m, T) -> (n_windows, m, m, F) or (n_rec, n_windows, ...)."""
+    eng = engine or default_engine()
+    x = np.asarray(x, dtype=np.float64)
+    single = x.ndim == 2
+    xd = eng.to_device(x[None] if single else x)
+    ff = sliding_ffdtf_device(xd, window_size, n_windows, p, freqs, fs, eng).cpu().numpy()
+    return ff[0] if single else ff

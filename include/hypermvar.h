@@ -1,0 +1,101 @@
+/* hypermvar -- C ABI of the MI355X (gfx950) sliding-window MVAR / ffDTF engine.
+ *
+ * This is the drop-in boundary for the hot path of the reference project
+ * (SYNCC-IN/hyperscanning-signal-analysis, src/mtmvar.py:35-284, 551-601).  The reference is pure
+ * Python/NumPy and has no FFI of its own; the "operator API" it exposes is the set of Python function
+ * signatures in src/mtmvar.py.  Each entry point below names the reference function whose arithmetic it
+ * replaces; `INTEGRATION.md` shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch-ROCm `tensor.data_ptr()`), float64 unless noted;
+ *   - buffers are caller-allocated and caller-owned; the library never allocates, frees or retains them;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 = launched, < 0 = bad argument (see hmv_last_error()), > 0 = hipError_t;
+ *   - numerical failures are reported per item through `info` arrays (LAPACK style: 0 = ok,
+ *     k > 0 = zero / non-positive pivot met at column k); the Python layer turns them into
+ *     numpy.linalg.LinAlgError("Singular matrix") like the reference's np.linalg.solve / inv;
+ *   - channel counts are padded to MP = hmv_pad(m) = 16*ceil(m/16) <= 64 inside the library's
+ *     intermediate buffers ("MP layout"); user-facing outputs are unpadded.
+ */
+#ifndef HYPERMVAR_H
+#define HYPERMVAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMV_VERSION 100            /* 0.1.0 */
+#define HMV_MAX_CHANNELS 64
+#define HMV_MAX_ORDER 32
+
+int hmv_version(void);
+/* Thread-local text of the last argument error reported by this thread ("" if none). */
+const char* hmv_last_error(void);
+/* Padded channel count used by the MP-layout buffers, or -1 if m is unsupported (m < 1 or m > 64). */
+int hmv_pad(int m);
+/* Number of doubles of K2 scratch per item. */
+int64_t hmv_yw_workspace_doubles(int m, int p);
+
+/* K1.  R[item][l][MP][MP] = (1/n) X[:, :n-l] X[:, l:]^T for l = 0..p  (biased, not demeaned).
+ * Replaces count_corr (src/mtmvar.py:35-87; lags :57-59, lag 0 :72-73).
+ * x: [n_rec][m][ld-strided samples]; window `it` covers samples item_start[it] .. +n of recording
+ * item_rec[it] (int64 device arrays -- arbitrary starts, as produced by
+ * EEG_IBI_FFDTF_Pipeline._create_windows, src/eeg_alpha_ibi_ffdtf.py:451-518). */
+int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld,
+                   const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
+                   int m, int n, int p, double* R, void* stream);
+
+/* K2.  Yule-Walker solve.  Replaces ar_coeff (src/mtmvar.py:90-123).
+ * ar: [item][MP][MP][p] with ar[i][j][k] multiplying x_j(t-k-1) into x_i(t) (lag fastest: the
+ * reference's own (m, m, p) layout when m == MP); V: [item][MP][MP] residual covariance.
+ * vq_logdet (optional, may be NULL): [item][p] = log det V_q for model orders q = 1..p, all from the one
+ * factorisation at order p (what mvar_criterion, src/mtmvar.py:551-601, gets from p separate fits). */
+int hmv_yw_solve_f64(const double* R, int64_t n_items, int m, int p, double* ws,
+                     double* ar, double* V, double* vq_logdet, int32_t* info, void* stream);
+
+/* tw[f][k] = exp(-(k+1) * 2*pi*1j * freqs[f] / fs) as interleaved (re, im), k = 0..p-1
+ * (src/mtmvar.py:151-153, same operation order). */
+int hmv_twiddles_f64(const double* freqs, int F, double fs, int p, double* tw, void* stream);
+
+/* K3.  A(f) = I - sum_k ar[:, :, k] tw[f][k];  H(f) = inv(A(f)).
+ * Replaces mvar_transfer_function (src/mtmvar.py:126-162) and the |H|^2 of dtf_multivariate (:232).
+ * Optional outputs (NULL to skip), kernel-natural layout [item][f][MP][MP]:
+ *   P = |H|^2 with rowsum[item][f][MP] = sum_j |H_ij|^2 (required together), H, A (complex128 interleaved).
+ * pivot_tau: 1.0 = partial pivoting on |re|+|im| (LAPACK zgetrf's choice); 0 < tau < 1 keeps the diagonal
+ * pivot whenever it is within a factor tau of the column maximum.  info: [item*F + f]. */
+int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F,
+               double* P, double* rowsum, double* H, double* A, int32_t* info,
+               double pivot_tau, void* stream);
+
+/* K4.  out[item][i][j][f] = P[item][f][i][j] / sum_{j',f'} P[item][f'][i][j']   (normalise = 1)
+ * Replaces the normalisation loop of full_freq_dtf (src/mtmvar.py:281-283); normalise = 0 returns the
+ * plain |H|^2 of dtf_multivariate in the reference's (m, m, F) layout.  den: [item][MP] scratch/out. */
+int hmv_ffdtf_norm_f64(const double* P, const double* rowsum, double* den, double* out,
+                       int64_t n_items, int F, int m, int normalise, void* stream);
+
+/* complex128 [item][f][MP][MP] -> [item][m][m][F] (the reference's H / A / spectra array layout). */
+int hmv_transpose_c128(const double* in, double* out, int64_t n_items, int F, int m, void* stream);
+
+/* K5.  S[item][f] = H V H^T, plain transpose (src/mtmvar.py:199).  H, S complex128 [item][f][MP][MP]. */
+int hmv_spectra_f64(const double* H, const double* V, double* S, int64_t n_items, int m, int F, void* stream);
+
+/* Fused sliding-window path K1 -> K2 -> K3 -> K4 over all items, processed `chunk` items at a time so the
+ * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
+ * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].
+ * ar_out / V_out (optional): [n_items][MP][MP][p] / [n_items][MP][MP].
+ * info_yw: [n_items], info_tf: [n_items*F].  workspace: hmv_sliding_workspace_bytes(chunk, m, p, F) bytes. */
+int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F);
+int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
+                          const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
+                          int m, int n, int p, const double* freqs, int F, double fs,
+                          double* ffdtf, double* ar_out, double* V_out,
+                          int32_t* info_yw, int32_t* info_tf,
+                          void* workspace, int64_t workspace_bytes, int64_t chunk,
+                          double pivot_tau, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERMVAR_H */
