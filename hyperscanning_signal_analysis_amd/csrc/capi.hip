@@ -135,7 +135,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
                           const int64_t* item_start, int64_t n_items, int m, int n, int p,
                           const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
-                          int64_t chunk, double pivot_tau, void* stream) {
+                          int64_t chunk, double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
@@ -164,7 +164,10 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     if (rc) return rc;
     rc = hmv_yw_solve_f64(R, c, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, stream);
     if (rc) return rc;
+    const bool last = (i0 + chunk >= n_items);
+    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), S(stream));
     rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, stream);
+    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), S(stream));
     if (rc) return rc;
     rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, stream);
     if (rc) return rc;

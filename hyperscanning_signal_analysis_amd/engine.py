@@ -159,8 +159,12 @@ class Engine:
 
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
-                      check: bool = True, chunk: int | None = None):
-        """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4)."""
+                      check: bool = True, chunk: int | None = None, k3_events=None):
+        """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
+
+        k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
+        have been recorded once) which the library records around the dominant kernel.
+        """
         assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
         x = x if x.stride(2) == 1 else x.contiguous()
         n_rec, m, T = x.shape
@@ -182,7 +186,7 @@ class Engine:
                 x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
                 m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
                 info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau,
-                self.stream())
+                k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream())
         _lib.check(rc, "hmv_sliding_ffdtf_f64")
         if check:
             self.raise_on_info(info_yw, "yw")

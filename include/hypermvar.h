@@ -85,7 +85,10 @@ int hmv_spectra_f64(const double* H, const double* V, double* S, int64_t n_items
  * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].
  * ar_out / V_out (optional): [n_items][MP][MP][p] / [n_items][MP][MP].
- * info_yw: [n_items], info_tf: [n_items*F].  workspace: hmv_sliding_workspace_bytes(chunk, m, p, F) bytes. */
+ * info_yw: [n_items], info_tf: [n_items*F].  workspace: hmv_sliding_workspace_bytes(chunk, m, p, F) bytes.
+ * ev_k3_start / ev_k3_stop (optional hipEvent_t, NULL to skip) are recorded on `stream` right before
+ * and after the LAST chunk's K3 launch, so a caller can time the dominant kernel inside its own timed
+ * region without an extra synchronisation. */
 int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F);
 int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
@@ -93,7 +96,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf,
                           void* workspace, int64_t workspace_bytes, int64_t chunk,
-                          double pivot_tau, void* stream);
+                          double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream);
 
 #ifdef __cplusplus
 }

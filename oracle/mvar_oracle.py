@@ -27,7 +27,7 @@ __all__ = [
     "lag_covariances", "count_corr", "ar_coeff", "mvar_transfer_function",
     "mvar_transfer_function_loop", "dtf_multivariate", "full_freq_dtf",
     "full_freq_dtf_loop", "multivariate_spectra", "mvar_criterion",
-    "window_positions", "create_windows", "sliding_ffdtf", "synthetic_var_dyad",
+    "window_positions", "create_windows", "sliding_ffdtf",
 ]
 
 
@@ -227,46 +227,3 @@ def sliding_ffdtf(x, window_size, n_windows, p, freqs, fs, loop=False):
     """ffDTF of every window of one recording `(m, T)`; returns `(n_windows, m, m, F)`."""
     fn = full_freq_dtf_loop if loop else full_freq_dtf
     return np.stack([fn(w, freqs, fs, p) for w in create_windows(x, n_windows, window_size)])
-
-
-# --------------------------------------------------------------------------- workload
-def synthetic_var_dyad(dyad: int, m: int = 64, p: int = 8, T: int = 300_000, fs: float = 500.0,
-                       burn: int = 2000, density: float = 0.05, coupling: float = 0.05,
-                       target_radius: float = 0.95):
-    """Seeded stable VAR(p) recording used by bench and parity tests.
-
-    Diagonal AR(2) resonators (f0 ~ U(4, 40) Hz, r ~ U(0.80, 0.95)), sparse N(0,1)*coupling
-    off-diagonal terms on every lag, companion spectral radius rescaled to `target_radius`
-    (A_k <- A_k * g**k), unit-variance innovations, burn-in discarded, each channel z-scored.
-    This is the build's own workload generator, not reference code.
-    """
-    rng = np.random.default_rng(1234 + dyad)
-    A = np.zeros((p, m, m))
-    f0 = rng.uniform(4.0, 40.0, m)
-    r = rng.uniform(0.80, 0.95, m)
-    idx = np.arange(m)
-    A[0, idx, idx] = 2 * r * np.cos(2 * np.pi * f0 / fs)
-    if p > 1:
-        A[1, idx, idx] = -r ** 2
-    mask = rng.random((p, m, m)) < density
-    off = coupling * rng.standard_normal((p, m, m)) * mask
-    off[:, idx, idx] = 0.0
-    A += off
-    comp = np.zeros((m * p, m * p))
-    comp[:m, :] = np.concatenate(list(A), axis=1)
-    comp[m:, :-m] = np.eye(m * (p - 1))
-    rho = np.max(np.abs(np.linalg.eigvals(comp)))
-    g = min(1.0, target_radius / rho)
-    A = A * (g ** np.arange(1, p + 1))[:, None, None]
-    n_tot = T + burn
-    e = rng.standard_normal((n_tot, m))
-    x = np.zeros((n_tot, m))
-    At = np.ascontiguousarray(A.transpose(0, 2, 1))            # x[t] = sum_k x[t-k-1] @ At[k] + e[t]
-    for t in range(p, n_tot):
-        acc = e[t].copy()
-        for k in range(p):
-            acc += x[t - k - 1] @ At[k]
-        x[t] = acc
-    x = x[burn:].T
-    x = (x - x.mean(axis=1, keepdims=True)) / x.std(axis=1, keepdims=True)
-    return np.ascontiguousarray(x)

@@ -41,7 +41,7 @@ from src import mtmvar as ref  # noqa: E402  (the reference itself)
 sys.modules.setdefault("xarray", types.ModuleType("xarray"))
 from src import eeg_alpha_ibi_ffdtf as ref_pipe  # noqa: E402
 
-from oracle.mvar_oracle import synthetic_var_dyad  # noqa: E402  (workload generator only)
+from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad  # noqa: E402  (workload generator only)
 
 
 def quiet(fn, *a, **k):

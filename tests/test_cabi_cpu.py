@@ -1,0 +1,70 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/hypermvar.h
+declares, rejects bad arguments without touching a GPU, and the product never falls back to the oracle."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "hyperscanning_signal_analysis_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hyperscanning_signal_analysis_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j", "8"], check=True)
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "hypermvar.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hmv_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported(lib):
+    from hyperscanning_signal_analysis_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 12
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and include/hypermvar.h disagree"
+    for s in syms:
+        assert hasattr(lib, s)
+    assert lib.hmv_version() == 100
+
+
+def test_argument_checks_without_gpu(lib):
+    assert lib.hmv_pad(3) == 16 and lib.hmv_pad(16) == 16 and lib.hmv_pad(19) == 32 and lib.hmv_pad(64) == 64
+    assert lib.hmv_pad(0) == -1 and lib.hmv_pad(65) == -1
+    assert lib.hmv_yw_workspace_doubles(64, 8) == (2 * 45 + 16) * 64 * 64
+    assert lib.hmv_sliding_workspace_bytes(1, 64, 8, 256) > 8 * 64 * 64 * 256
+    # bad arguments are refused before any launch
+    assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 65, 100, 4, 0, 0) == -1
+    assert b"channel count" in lib.hmv_last_error()
+    assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 8, 100, 40, 0, 0) == -2
+    assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 8, 4, 4, 0, 0) == -3
+    assert lib.hmv_tf_f64(1, 1, 8, 2, 1, 4, 0, 0, 0, 0, 1, 1.5, 0) == -6
+
+
+def test_product_does_not_import_oracle_or_fall_back():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{f} mentions the oracle"
+    # engine refuses to run without a GPU instead of computing on the CPU
+    import torch
+    if not torch.cuda.is_available():
+        from hyperscanning_signal_analysis_amd.engine import Engine
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            Engine()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from hyperscanning_signal_analysis_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()

@@ -2,6 +2,7 @@ import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import mvar_oracle as O
+from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad
 from hyperscanning_signal_analysis_amd import mtmvar as M
 from hyperscanning_signal_analysis_amd.engine import default_engine
 from hyperscanning_signal_analysis_amd.sliding import sliding_ffdtf
