@@ -17,6 +17,12 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
+#ifdef HMV_STAMP
+// Diagnostic build only (never shipped, not in include/hypermvar.h): where K3 writes its phase stamps.
+static unsigned long long* g_tf_stamps = nullptr;
+extern "C" void hmv_debug_set_tf_stamps(void* p) { g_tf_stamps = static_cast<unsigned long long*>(p); }
+#endif
+
 extern "C" {
 
 int hmv_version(void) { return HMV_VERSION; }
@@ -73,6 +79,10 @@ int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw
   hmv::TfArgs a;
   a.ar = ar; a.tw = tw; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
   a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
+  a.stamps = nullptr;
+#ifdef HMV_STAMP
+  a.stamps = g_tf_stamps;
+#endif
   return hmv::launch_tf_inv(a, mp, S(stream));
 }
 

@@ -76,6 +76,45 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
   return k;
 }
 
+// ---- DPP helpers (gfx9-family controls: quad_perm, row_half_mirror, row_mirror) ------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+// max over each row of 16 lanes, result in all 16 lanes (4 VALU+DPP steps, no LDS traffic)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  unsigned o;
+  o = dpp_u32<0xB1>(v); v = o > v ? o : v;    // quad_perm [1,0,3,2]
+  o = dpp_u32<0x4E>(v); v = o > v ? o : v;    // quad_perm [2,3,0,1]
+  o = dpp_u32<0x141>(v); v = o > v ? o : v;   // row_half_mirror
+  o = dpp_u32<0x140>(v); v = o > v ? o : v;   // row_mirror
+  return v;
+}
+// wave-uniform max of a 32-bit key over the 64 lanes (returned in an SGPR)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = row16_max_u32(v);
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xf, 0xf, false);
+  u.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xf, 0xf, false);
+  return u.d;
+}
+// sum over each row of 16 lanes via DPP (fixed order => deterministic), result in all 16 lanes
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  return v;
+}
+
 // sum over the 16 lanes that share l >> 4 (all 16 receive the result)
 __device__ __forceinline__ double row16_sum(double v) {
   const int l = lane_id();

@@ -44,6 +44,7 @@ struct TfArgs {
   long long n_items;
   int F, p, m;
   double tau;               // pivot threshold: 1.0 = LAPACK partial pivoting
+  unsigned long long* stamps;   // diagnostic builds (-DHMV_STAMP) only: [wave][8] phase cycle sums; else null
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
 int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);

@@ -38,6 +38,21 @@ namespace hmv {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 
+// Phase stamps for the diagnostic build (-DHMV_STAMP): shares of a matrix's life, never its length.
+#ifdef HMV_STAMP
+#define HMV_T(idx)                                                                     \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long t_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    tsum[idx] += t_ - tlast;                                                           \
+    tlast = t_;                                                                        \
+  } while (0)
+#else
+#define HMV_T(idx) do { } while (0)
+#endif
+
 template <int NT>
 struct TfLds {
   static constexpr int MP = 16 * NT;
@@ -68,45 +83,87 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
   double2* bufB = bufA + L::ROWB;
 
   double re[NI][NJ], im[NI][NJ];
+#ifdef HMV_STAMP
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
 
   // ---------------------------------------------------------------- A(f)
   {
     const double* ar = a.ar + (size_t)item * MP * MP * p;
     const double* tw = a.tw + (size_t)f * p * 2;
+    // Lag chunks of KC coefficients: a batch of 2 row blocks x NJ column groups issues all of its
+    // 16-byte loads back to back (explicit staging array -- left to itself the register allocator
+    // serialises every load behind an s_waitcnt), then runs the FMAs.  KC = 8 reads each element's
+    // 64 contiguous bytes exactly once (full 128-B lines, L2 -> L1 traffic = the 256 KB once).
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        re[I][J] = (4 * I + i == 16 * J + cc) ? 1.0 : 0.0;
+        im[I][J] = 0.0;
+      }
+    const double* e0 = ar + ((size_t)i * MP + cc) * p;
+    auto chunk = [&](auto kc_tag, int k0) __attribute__((always_inline)) {
+      constexpr int KC = decltype(kc_tag)::value;            // 8, 4 or 2 lags, 16-byte loads
+      double zr[KC], zi[KC];
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        zr[k] = tw[2 * (k0 + k)];
+        zi[k] = tw[2 * (k0 + k) + 1];
+      }
+      static_for<NI / 2>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int I0 = 2 * decltype(ic)::value;
+        double2 v[2][NJ][KC / 2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            const double2* e = reinterpret_cast<const double2*>(e0 + ((size_t)(4 * (I0 + d)) * MP + 16 * J) * p + k0);
+#pragma unroll
+            for (int h = 0; h < KC / 2; ++h) v[d][J][h] = e[h];
+          }
+        __builtin_amdgcn_sched_barrier(0);   // all loads of the batch are in flight before the first FMA
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            double sr = re[I0 + d][J], si = im[I0 + d][J];
+#pragma unroll
+            for (int h = 0; h < KC / 2; ++h) {
+              sr = __builtin_fma(-v[d][J][h].x, zr[2 * h], sr);
+              si = __builtin_fma(-v[d][J][h].x, zi[2 * h], si);
+              sr = __builtin_fma(-v[d][J][h].y, zr[2 * h + 1], sr);
+              si = __builtin_fma(-v[d][J][h].y, zi[2 * h + 1], si);
+            }
+            re[I0 + d][J] = sr;
+            im[I0 + d][J] = si;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    int k0 = 0;
     if ((p & 1) == 0) {
+      for (; k0 + 8 <= p; k0 += 8) chunk(std::integral_constant<int, 8>{}, k0);
+      for (; k0 + 2 <= p; k0 += 2) chunk(std::integral_constant<int, 2>{}, k0);
+    }
+    for (; k0 < p; ++k0) {
+      const double zr = tw[2 * k0], zi = tw[2 * k0 + 1];
+      static_for<NI / 2>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int I0 = 2 * decltype(ic)::value;
+        double v[2][NJ];
 #pragma unroll
-      for (int I = 0; I < NI; ++I)
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int J = 0; J < NJ; ++J) {
-          const int row = 4 * I + i, col = 16 * J + cc;
-          const double2* e = reinterpret_cast<const double2*>(ar + ((size_t)row * MP + col) * p);
-          double sr = (row == col) ? 1.0 : 0.0, si = 0.0;
-          for (int k = 0; k < p; k += 2) {
-            const double2 v = e[k >> 1];
-            sr = __builtin_fma(-v.x, tw[2 * k], sr);
-            si = __builtin_fma(-v.x, tw[2 * k + 1], si);
-            sr = __builtin_fma(-v.y, tw[2 * k + 2], sr);
-            si = __builtin_fma(-v.y, tw[2 * k + 3], si);
+          for (int J = 0; J < NJ; ++J) v[d][J] = e0[((size_t)(4 * (I0 + d)) * MP + 16 * J) * p + k0];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) {
+            re[I0 + d][J] = __builtin_fma(-v[d][J], zr, re[I0 + d][J]);
+            im[I0 + d][J] = __builtin_fma(-v[d][J], zi, im[I0 + d][J]);
           }
-          re[I][J] = sr;
-          im[I][J] = si;
-        }
-    } else {
-#pragma unroll
-      for (int I = 0; I < NI; ++I)
-#pragma unroll
-        for (int J = 0; J < NJ; ++J) {
-          const int row = 4 * I + i, col = 16 * J + cc;
-          const double* e = ar + ((size_t)row * MP + col) * p;
-          double sr = (row == col) ? 1.0 : 0.0, si = 0.0;
-          for (int k = 0; k < p; ++k) {
-            const double v = e[k];
-            sr = __builtin_fma(-v, tw[2 * k], sr);
-            si = __builtin_fma(-v, tw[2 * k + 1], si);
-          }
-          re[I][J] = sr;
-          im[I][J] = si;
-        }
+      });
     }
     if (a.A) {
       double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP;
@@ -117,6 +174,7 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
     }
   }
 
+  HMV_T(0);
   int orig = l;    // lane c: original row index now sitting in row c
   int info = 0;
   const double tau = a.tau;
@@ -142,21 +200,24 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
       }
     }
     int swp[4];
+    HMV_T(1);
     // 2. four pivot steps inside the panel
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * s + jj;
       const double cand = (l >= col && l < MP) ? (__builtin_fabs(xr[jj]) + __builtin_fabs(xi[jj])) : -1.0;
-      const unsigned long long key =
-          (cand < 0.0) ? 0ull : (((unsigned long long)__double_as_longlong(cand) & ~63ull) | (unsigned long long)(63 - l));
-      const unsigned long long kmax = wave_max_u64(key);
-      int rstar = uni(63 - (int)(kmax & 63ull));
-      const double vmax = __longlong_as_double((long long)(kmax & ~63ull));
+      // arg-max of |re|+|im| over the not-yet-pivoted rows: float-rounded magnitude as a 32-bit key
+      // (monotonic for non-negative floats), DPP max, then the lowest lane holding the maximum.
+      const unsigned key = (cand < 0.0) ? 0u : __float_as_uint((float)cand);
+      const unsigned kmax = wave_max_u32(key);
+      const unsigned long long hit = __ballot(key == kmax);
+      int rstar = uni(kmax == 0u ? col : (int)__builtin_ctzll(hit));
+      const double vmax = readlane_f64(cand, rstar);
       if (tau < 1.0) {
         const double dc = readlane_f64(cand, col);
         if (dc >= tau * vmax) rstar = col;
       }
-      if (vmax == 0.0 && info == 0) info = col + 1;
+      if (!(vmax > 0.0) && info == 0) info = col + 1;
       swp[jj] = rstar;
       if (rstar != col) {
 #pragma unroll
@@ -170,7 +231,10 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
         orig = (l == col) ? orr : ((l == rstar) ? oc : orig);
       }
       const double pr = readlane_f64(xr[jj], col), pi = readlane_f64(xi[jj], col);
-      const double invd = 1.0 / (pr * pr + pi * pi);
+      const double dd = pr * pr + pi * pi;
+      double invd = __builtin_amdgcn_rcp(dd);                    // v_rcp_f64 seed + 2 Newton steps
+      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
+      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
       const double ivr = pr * invd, ivi = -pi * invd;
       double qr[4], qi[4];
 #pragma unroll
@@ -195,6 +259,7 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
         xi[j2] = isp ? qi[j2] : ni;
       }
     }
+    HMV_T(2);
     // N = M'[:, S] in lane-per-row layout -> LDS (A-operand source and panel write-back source)
     if (l < MP) {
 #pragma unroll
@@ -241,6 +306,7 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
       }
     }
     HMV_WAVE_SYNC();
+    HMV_T(3);
     // 4. rank-4 update on the matrix cores
     double ur[NJ], ui[NJ];
 #pragma unroll
@@ -248,9 +314,14 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
       ur[J] = re[s][J];
       ui[J] = im[s][J];
     }
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {
-      const double2 nv = Nbuf[(4 * I + (l & 3)) * 4 + (l >> 4)];
+    // A operand of row block I+1 is fetched from LDS before the 16 MFMAs of row block I are issued,
+    // so its ~100-cycle latency hides behind them (in-order issue: the read must precede them).
+    double2 nvn = Nbuf[(l & 3) * 4 + (l >> 4)];
+    static_for<NI>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      const double2 nv = nvn;
+      if (I + 1 < NI) nvn = Nbuf[(4 * (I + 1) + (l & 3)) * 4 + (l >> 4)];
+      __builtin_amdgcn_sched_barrier(0);
       double nr = nv.x;
       const double ni = nv.y;
       if (I == s) nr -= ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
@@ -263,7 +334,8 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
       for (int J = 0; J < NJ; ++J) re[I][J] = mfma4(nni, ui[J], re[I][J]);
 #pragma unroll
       for (int J = 0; J < NJ; ++J) im[I][J] = mfma4(ni, ur[J], im[I][J]);
-    }
+    });
+    HMV_T(4);
     // 5. panel columns <- N
     if ((cc >> 2) == q) {
 #pragma unroll
@@ -274,6 +346,7 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
       }
     }
     HMV_WAVE_SYNC();
+    HMV_T(5);
   });
 
   // ---------------------------------------------------------------- outputs
@@ -302,10 +375,16 @@ __global__ void __launch_bounds__(256, 1) tf_inv_kernel(TfArgs a) {
         Po[(size_t)(4 * I + i) * MP + oc[J]] = v;
         acc += v;
       }
-      acc = row16_sum(acc);
+      acc = row16_sum_dpp(acc);
       if (cc == 0) rs[4 * I + i] = acc;
     }
   }
+#ifdef HMV_STAMP
+  HMV_T(6);
+  if (a.stamps && l == 0) {
+    for (int k = 0; k < 8; ++k) a.stamps[gw * 8 + k] = tsum[k];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- twiddles

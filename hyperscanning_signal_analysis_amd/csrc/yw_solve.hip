@@ -50,6 +50,8 @@ __device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double
   constexpr int MP = 16 * NT, NI = 4 * NT, NJ = NT, NSTEP = MP / 4;
   const int l = lane_id();
   const int i = l >> 4, cc = l & 15;
+  double mypiv = 1.0;   // lane c keeps pivot c; ONE log per lane after the sweep (log() inlined per column
+                        // costs ~100 VGPRs and thousands of instructions)
   static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
     constexpr int Js = s >> 2, q = s & 3;
@@ -69,7 +71,7 @@ __device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double
       const int col = 4 * s + jj;
       const double piv = readlane_f64(x[jj], col);
       if (!(piv > 0.0) && info == 0) info = col + 1;
-      if (want_logdet) logdet += log(piv);
+      mypiv = (l == col) ? piv : mypiv;
       const double inv = 1.0 / piv;
       double qv[4];
 #pragma unroll
@@ -104,10 +106,14 @@ __device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double
     }
     HMV_WAVE_SYNC();
   });
+  if (want_logdet) {
+    double v = row16_sum_dpp(log(mypiv));          // padded lanes hold 1.0 -> log = 0
+    logdet = readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
+  }
 }
 
 template <int NT>
-__global__ void __launch_bounds__(256) yw_kernel(YwArgs a) {
+__global__ void __launch_bounds__(256, 2) yw_kernel(YwArgs a) {
   using C = YwCfg<NT>;
   constexpr int MP = C::MP, S = C::S, NIW = NT, NJ = NT;
   constexpr int TILE = MP * MP;
@@ -131,12 +137,22 @@ __global__ void __launch_bounds__(256) yw_kernel(YwArgs a) {
   int info = 0;
 
   // ---- helpers -------------------------------------------------------------------------------
-  auto stage = [&](double* dst, const double* src, bool transpose) {
-    for (int idx = threadIdx.x; idx < TILE; idx += 256) {
+  // Both operand tiles of a product are fetched with ALL loads in flight before the first LDS store
+  // (a load->store loop serialises on the ~1 us global latency 16 times per tile).
+  constexpr int NPT = TILE / 256;   // elements per thread per tile (1, 4, 9, 16)
+  auto stage2 = [&](const double* srcX, bool trX, const double* srcY, bool trY) {
+    double vx[NPT], vy[NPT];
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) vx[r] = srcX ? srcX[threadIdx.x + 256 * r] : 0.0;
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) vy[r] = srcY[threadIdx.x + 256 * r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+      const int idx = threadIdx.x + 256 * r;
       const int row = idx / MP, col = idx - row * MP;
-      const double v = src[idx];
-      if (transpose) dst[col * S + row] = v;
-      else dst[row * S + col] = v;
+      if (srcX) Xs[trX ? col * S + row : row * S + col] = vx[r];
+      Ys[trY ? col * S + row : row * S + col] = vy[r];
     }
   };
   // acc[ii][J] += Xs(rows of this wave) * Ys^T
@@ -206,8 +222,7 @@ __global__ void __launch_bounds__(256) yw_kernel(YwArgs a) {
         }
       for (int c = 0; c < tb; ++c) {
         __syncthreads();
-        stage(Xs, Lt + yw_tri(ta, c) * TILE, false);
-        stage(Ys, Yt + yw_tri(tb, c) * TILE, false);
+        stage2(Lt + yw_tri(ta, c) * TILE, false, Yt + yw_tri(tb, c) * TILE, false);
         __syncthreads();
         gemm_nt(acc);
         if (a.Vq_logdet && ta == p && tb == p) {   // V_{c+1} = R_0 - sum_{c' <= c} ...
@@ -231,7 +246,7 @@ __global__ void __launch_bounds__(256) yw_kernel(YwArgs a) {
         store_tile(Yt + yw_tri(ta, tb) * TILE, g);
         __syncthreads();
         strip_to_lds(Xs, g);
-        stage(Ys, Dinv + (size_t)tb * TILE, true);
+        stage2(nullptr, false, Dinv + (size_t)tb * TILE, true);
         __syncthreads();
 #pragma unroll
         for (int ii = 0; ii < NIW; ++ii)
@@ -264,8 +279,7 @@ __global__ void __launch_bounds__(256) yw_kernel(YwArgs a) {
       }
     for (int c = tb + 1; c < p; ++c) {
       __syncthreads();
-      stage(Xs, Zt + (size_t)c * TILE, false);
-      stage(Ys, Lt + yw_tri(c, tb) * TILE, true);
+      stage2(Zt + (size_t)c * TILE, false, Lt + yw_tri(c, tb) * TILE, true);
       __syncthreads();
       gemm_nt(acc);
     }
