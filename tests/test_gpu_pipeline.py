@@ -1,0 +1,73 @@
+"""EEG_IBI_FFDTF_Pipeline mirror end to end on the GPU with synthetic recordings (config 4 of
+BASELINE.json): .npz layout of the reference (eeg_alpha_ibi_ffdtf.py:637-658) and parity of every
+window with the oracle on the same pre-processed block."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mvar_oracle as O
+from tests.test_pipeline_cpu import make_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def synthetic_loader(eeg_file, ibi_file, role):
+    seed = abs(hash((eeg_file.name, role))) % (2 ** 31)
+    rng = np.random.default_rng(seed)
+    fs = 128.0
+    n = int(80 * fs)
+    t = np.arange(n) / fs
+    names = ["Fp1", "Fp2", "F3", "F4", "C3", "C4", "P3", "P4", "O1", "O2", "F7", "F8", "T3", "T4", "T5", "T6", "Fz", "Cz", "Pz"]
+    eeg = rng.standard_normal((19, n))
+    eeg[2] += (1.5 + np.sin(2 * np.pi * 0.21 * t)) * np.sin(2 * np.pi * 10 * t)
+    eeg[3] += (1.5 + np.cos(2 * np.pi * 0.13 * t)) * np.sin(2 * np.pi * 10.5 * t)
+    ibi = 0.8 + 0.05 * np.sin(2 * np.pi * 0.25 * t) + 0.01 * np.cumsum(rng.standard_normal(n)) / np.sqrt(n)
+    return t, eeg, fs, names, ibi[None, :], fs, 80.0
+
+
+def test_run_pipeline_matches_oracle(tmp_path):
+    from hyperscanning_signal_analysis_amd.eeg_alpha_ibi_ffdtf import EEG_IBI_FFDTF_Pipeline
+    root = make_tree(tmp_path / "data", dyads=("W_001", "W_002"), films=("Peppa",),
+                     skip={("IBI", "W_002", "cg", "Peppa")})
+    out = tmp_path / "out"
+    pipe = EEG_IBI_FFDTF_Pipeline(root, out, ["Peppa"], n_windows=5, window_size=160, ar_p=5,
+                                  plot_global_enabled=False, save_global_enabled=False,
+                                  plot_windowed_enabled=False, save_windowed_enabled=False,
+                                  loader=synthetic_loader)
+    pipe.run_pipeline()
+    assert not (out / "W_002").exists()                              # missing file -> [SKIP]
+    z = np.load(out / "W_001" / "W_001_Peppa_ffDTF.npz", allow_pickle=False)
+    assert sorted(z.files) == sorted(["ff_dtf_global", "spectra_global", "ff_dtf_windowed", "spectra_windowed",
+                                      "p_opt_g", "p_opt_w", "meta"])
+    assert z["ff_dtf_windowed"].shape == (5, 4, 4, 30) and z["spectra_windowed"].dtype == np.complex128
+    assert z["ff_dtf_global"].shape == (4, 4, 30) and int(z["p_opt_g"]) == 5 and list(z["p_opt_w"]) == [5] * 5
+    meta = json.loads(str(z["meta"]))
+    assert meta["chan_names"] == ["faa_ch", "ibi_ch", "faa_cg", "ibi_cg"] and meta["fs"] == 8.0
+    # rebuild the 4 x 480 block with the pipeline's own host DSP and check the GPU numerics against the oracle
+    blocks = []
+    for role, rname in (("ch", "Child"), ("cg", "Care Giver")):
+        _, eeg, fs, names, ibi, fs_ibi, _ = synthetic_loader(root / "EEG" / "W_001" / ("child" if role == "ch" else "caregiver") / f"W_001_EEG_{role}_Peppa.nc", None, rname)
+        faa, ibic = pipe._preprocess(eeg, fs, names, ibi, fs_ibi)
+        blocks += [faa, ibic]
+    sig = np.vstack(blocks)
+    sig = (sig - sig.mean(axis=1, keepdims=True)) / sig.std(axis=1, keepdims=True)
+    freqs = np.arange(1.0, (8.0 / 2 - 0.1) + 0.1, 0.1)
+    for k, w in enumerate(O.create_windows(sig, 5, 160)):
+        assert np.allclose(z["ff_dtf_windowed"][k], O.full_freq_dtf(w, freqs, 8.0, 5), rtol=1e-7, atol=1e-12)
+        ref = O.multivariate_spectra(w, freqs, 8.0, 5)
+        assert np.abs(z["spectra_windowed"][k] - ref).max() <= 1e-8 * np.abs(ref).max()
+    assert np.allclose(z["ff_dtf_global"], O.full_freq_dtf(sig, freqs, 8.0, 5), rtol=1e-7, atol=1e-12)
+
+
+def test_order_selection_path(tmp_path):
+    from hyperscanning_signal_analysis_amd.eeg_alpha_ibi_ffdtf import EEG_IBI_FFDTF_Pipeline
+    root = make_tree(tmp_path / "data", dyads=("W_001",), films=("Peppa",))
+    pipe = EEG_IBI_FFDTF_Pipeline(root, tmp_path / "out", ["Peppa"], ar_p=None, loader=synthetic_loader)
+    x = np.random.default_rng(1).standard_normal((4, 480))
+    x[:, 1:] += 0.5 * x[:, :-1]
+    ff, sp, p_opt = pipe._compute_ffDTF("D", x, list("abcd"), 8.0, plot=False)
+    _, _, want = O.mvar_criterion(x, 20, "AIC")
+    assert int(p_opt) == int(want)
+    assert np.allclose(ff, O.full_freq_dtf(x, pipe._freqs(), 8.0, int(want)), rtol=1e-7, atol=1e-12)
