@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   // resident panel factorisations (one wave each) queue on ONE SIMD while the other three idle.
   const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;   // hashed: block ids on one CU share low bits
   const long long gw = blockIdx.x;              // item * F + f
-  const long long item = gw / a.F;
-  const int f = (int)(gw - item * a.F);
+  const int item = uni((int)(blockIdx.x / (unsigned)a.F));   // wave-uniform: keep it in SGPRs
+  const int f = uni((int)(blockIdx.x - (unsigned)item * (unsigned)a.F));
   const int p = a.p;
   const int i = l >> 4, cc = l & 15;
   const int mycol = 16 * w + cc;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       im[I] = 0.0;
     }
     const double* e0 = ar + ((size_t)i * MP + mycol) * p;
-    // Lag chunks of KC coefficients; a batch of 4 row blocks issues all of its 16-byte loads before the
+    // Lag chunks of KC coefficients; a batch of 2-4 row blocks issues all of its 16-byte loads before the
     // first FMA (explicit staging array + sched_barrier: left alone the compiler serialises every load
     // behind an s_waitcnt).  KC = 8 reads each element's 64 contiguous bytes exactly once.
     auto chunk = [&](auto kc_tag, int k0) __attribute__((always_inline)) {
@@ -111,18 +111,19 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         zr[k] = tw[2 * (k0 + k)];
         zi[k] = tw[2 * (k0 + k) + 1];
       }
-      static_for<NI / 4>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int I0 = 4 * decltype(ic)::value;
-        double2 v[4][KC / 2];
+      constexpr int NB = (KC >= 8) ? 2 : 4;                  // row blocks per batch (register budget: 128 VGPRs)
+      static_for<NI / NB>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int I0 = NB * decltype(ic)::value;
+        double2 v[NB][KC / 2];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < NB; ++d) {
           const double2* e = reinterpret_cast<const double2*>(e0 + (size_t)(4 * (I0 + d)) * MP * p + k0);
 #pragma unroll
           for (int h = 0; h < KC / 2; ++h) v[d][h] = e[h];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < NB; ++d) {
           double sr = re[I0 + d], si = im[I0 + d];
 #pragma unroll
           for (int h = 0; h < KC / 2; ++h) {
@@ -333,29 +334,35 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   });
 
   // ---------------------------------------------------------------- outputs
-  const int oc = s_orig[mycol];      // last written before the final barrier of the sweep
+  // Lane coordinates are re-derived from an opaque lane id: reusing `i` would keep the 15 row indices
+  // 4I+i of the prologue alive across the whole sweep (they were spilled to scratch: 2.5 GB per launch).
+  int lo;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+  const int io = lo >> 4, cco = lo & 15;
+  const int oc = s_orig[16 * w + cco];      // last written before the final barrier of the sweep
   if (w == 0 && l == 0) a.info[gw] = s_info;
 
   if (a.H) {
-    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP;
+    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)io * MP + oc;
 #pragma unroll
-    for (int I = 0; I < NI; ++I) Ho[(size_t)(4 * I + i) * MP + oc] = make_double2(re[I], im[I]);
+    for (int I = 0; I < NI; ++I) Ho[(size_t)(4 * I) * MP] = make_double2(re[I], im[I]);
   }
   if (a.P) {
-    double* Po = a.P + (size_t)gw * MP * MP;
+    double* Po = a.P + (size_t)gw * MP * MP + (size_t)io * MP + oc;
+    double* rs = rsum + w * MP + io;
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
       const double v = re[I] * re[I] + im[I] * im[I];
-      Po[(size_t)(4 * I + i) * MP + oc] = v;
+      Po[(size_t)(4 * I) * MP] = v;
       const double acc = row16_sum_dpp(v);
-      if (cc == 0) rsum[w * MP + 4 * I + i] = acc;
+      if (cco == 0) rs[4 * I] = acc;
     }
     __syncthreads();
-    if (w == 0 && l < MP) {
+    if (w == 0 && lo < MP) {
       double t = 0.0;
 #pragma unroll
-      for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + l];   // fixed order: bit-reproducible
-      a.rowsum[(size_t)gw * MP + l] = t;
+      for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // fixed order: bit-reproducible
+      a.rowsum[(size_t)gw * MP + lo] = t;
     }
   }
 }
