@@ -81,13 +81,20 @@ template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
 }
-// max over each row of 16 lanes, result in all 16 lanes (4 VALU+DPP steps, no LDS traffic)
+// max over each row of 16 lanes, result in all 16 lanes: four v_max_u32 with a DPP source operand (the
+// builtin form costs v_mov + s_nop + v_mov_dpp + v_max per step).  The s_nop 1 pairs are the two wait
+// states a DPP read needs after a VALU write of its source; hipcc pads nothing inside an asm statement.
 __device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
-  unsigned o;
-  o = dpp_u32<0xB1>(v); v = o > v ? o : v;    // quad_perm [1,0,3,2]
-  o = dpp_u32<0x4E>(v); v = o > v ? o : v;    // quad_perm [2,3,0,1]
-  o = dpp_u32<0x141>(v); v = o > v ? o : v;   // row_half_mirror
-  o = dpp_u32<0x140>(v); v = o > v ? o : v;   // row_mirror
+  asm("s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return v;
 }
 // wave-uniform max of a 32-bit key over the 64 lanes (returned in an SGPR)

@@ -20,7 +20,7 @@ constexpr int LC_HALO = 32;    // max lag
 constexpr int LC_S = LC_TC + LC_HALO + 6;   // 134 = 6 (mod 32)
 
 template <int NT>
-__global__ void __launch_bounds__(256) lagcov_kernel(LagcovArgs a) {
+__global__ void __launch_bounds__(256, 2) lagcov_kernel(LagcovArgs a) {
   constexpr int MP = 16 * NT, NI = 4 * NT, NJ = NT;
   __shared__ double xs[MP * LC_S];
   const int l = lane_id();

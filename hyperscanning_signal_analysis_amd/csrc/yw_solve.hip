@@ -17,10 +17,13 @@
 // (semi)definite, so no pivoting is needed; a non-positive pivot is reported through `info` and becomes
 // numpy.linalg.LinAlgError("Singular matrix") in the Python layer, like the reference's dgesv failure.
 //
-// Mapping: one workgroup (4 waves) per window.  Every tile product is an MP x MP x MP real GEMM on
-// v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row stride 6 mod 32 doubles: conflict-free
-// A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the output tile.  The p tile
-// inverses D_b^-1 run on wave 0 as an in-register blocked Gauss-Jordan (same scheme as K3, real, no pivot).
+// Mapping: one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by tile
+// column (diagonal tile kernel, then all tiles below it), the back substitution pivot block by pivot block,
+// so a batch of a few hundred windows still fills the chip.  Every tile product is an MP x MP x MP real
+// GEMM on v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row stride 6 mod 32 doubles:
+// conflict-free A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the output tile.  The
+// p tile inverses D_b^-1 run on wave 0 as an in-register blocked Gauss-Jordan (same scheme as K3, real, no
+// pivot).
 #include "hmv_common.h"
 #include "hmv_kernels.h"
 
@@ -112,35 +115,24 @@ __device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double
   }
 }
 
+// Shared pieces of the three kernels: tile staging, the MP^3 tile product, tile I/O in the D layout.
 template <int NT>
-__global__ void __launch_bounds__(256, 2) yw_kernel(YwArgs a) {
+struct YwTile {
   using C = YwCfg<NT>;
-  constexpr int MP = C::MP, S = C::S, NIW = NT, NJ = NT;
-  constexpr int TILE = MP * MP;
-  __shared__ double Xs[MP * S];
-  __shared__ double Ys[MP * S];
-  __shared__ double Pb[MP * 4];
-  __shared__ double Nb[MP * 4];
+  static constexpr int MP = C::MP, S = C::S, NIW = NT, NJ = NT, TILE = MP * MP, NPT = TILE / 256;
+  double* Xs;
+  double* Ys;
+  int l, wv, i, cc;
 
-  const int l = lane_id();
-  const int wv = uni(threadIdx.x >> 6);
-  const int i = l >> 4, cc = l & 15;
-  const long long item = blockIdx.x;
-  const int p = a.p;
-  const double* R = a.R + (size_t)item * (p + 1) * TILE;
-  double* ws = a.ws + (size_t)item * yw_ws_tiles_d(p) * TILE;
-  const long long ntri = yw_tri(p + 1, 0);
-  double* Yt = ws;                      // Y tiles  (lower triangle)
-  double* Lt = ws + ntri * TILE;        // Lt tiles (lower triangle)
-  double* Dinv = ws + 2 * ntri * TILE;  // p tiles
-  double* Zt = Dinv + (size_t)p * TILE; // p tiles
-  int info = 0;
-
-  // ---- helpers -------------------------------------------------------------------------------
+  __device__ __forceinline__ YwTile(double* xs, double* ys) : Xs(xs), Ys(ys) {
+    l = lane_id();
+    wv = uni(threadIdx.x >> 6);
+    i = l >> 4;
+    cc = l & 15;
+  }
   // Both operand tiles of a product are fetched with ALL loads in flight before the first LDS store
   // (a load->store loop serialises on the ~1 us global latency 16 times per tile).
-  constexpr int NPT = TILE / 256;   // elements per thread per tile (1, 4, 9, 16)
-  auto stage2 = [&](const double* srcX, bool trX, const double* srcY, bool trY) {
+  __device__ __forceinline__ void stage2(const double* srcX, bool trX, const double* srcY, bool trY) const {
     double vx[NPT], vy[NPT];
 #pragma unroll
     for (int r = 0; r < NPT; ++r) vx[r] = srcX ? srcX[threadIdx.x + 256 * r] : 0.0;
@@ -154,9 +146,9 @@ __global__ void __launch_bounds__(256, 2) yw_kernel(YwArgs a) {
       if (srcX) Xs[trX ? col * S + row : row * S + col] = vx[r];
       Ys[trY ? col * S + row : row * S + col] = vy[r];
     }
-  };
+  }
   // acc[ii][J] += Xs(rows of this wave) * Ys^T
-  auto gemm_nt = [&](double (&acc)[NIW][NJ]) {
+  __device__ __forceinline__ void gemm_nt(double (&acc)[NIW][NJ]) const {
     const double* xa = Xs + (4 * wv * NT + (l & 3)) * S + (l >> 4);
     const double* yb = Ys + cc * S + (l >> 4);
 #pragma unroll 2
@@ -171,145 +163,239 @@ __global__ void __launch_bounds__(256, 2) yw_kernel(YwArgs a) {
 #pragma unroll
         for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[ii], bv[J], acc[ii][J]);
     }
-  };
-  auto store_tile = [&](double* dst, const double (&v)[NIW][NJ]) {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) dst[(size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc] = v[ii][J];
-  };
-  auto strip_to_lds = [&](double* dst, const double (&v)[NIW][NJ]) {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) dst[(4 * (wv * NT + ii) + i) * S + 16 * J + cc] = v[ii][J];
-  };
-  // wave 0: log det of the SPD tile currently in Xs (all strips written, barrier passed)
-  auto tile_inverse_from_Xs = [&](double* dinv_out, double* logdet_out) {
-    if (wv == 0) {
-      double t[4 * NT][NT];
-#pragma unroll
-      for (int I = 0; I < 4 * NT; ++I)
-#pragma unroll
-        for (int J = 0; J < NT; ++J) t[I][J] = Xs[(4 * I + i) * S + 16 * J + cc];
-      double ld = 0.0;
-      spd_inverse_wave<NT>(t, Pb, Nb, info, ld, logdet_out != nullptr);
-      if (dinv_out) {
-#pragma unroll
-        for (int I = 0; I < 4 * NT; ++I)
-#pragma unroll
-          for (int J = 0; J < NT; ++J) dinv_out[(size_t)(4 * I + i) * MP + 16 * J + cc] = t[I][J];
-      }
-      if (logdet_out && l == 0) *logdet_out = ld;
-    }
-  };
-
-  // ---- block LDL^T, left-looking ----------------------------------------------------------------
-  for (int ta = 0; ta <= p; ++ta) {
-    for (int tb = 0; tb <= ta; ++tb) {
-      double g[NIW][NJ], acc[NIW][NJ];
-#pragma unroll
-      for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-        for (int J = 0; J < NJ; ++J) {
-          const int row = 4 * (wv * NT + ii) + i, col = 16 * J + cc;
-          double v;
-          if (ta < p) v = R[(size_t)(ta - tb) * TILE + row * MP + col];
-          else if (tb < p) v = R[(size_t)(tb + 1) * TILE + col * MP + row];
-          else v = R[row * MP + col];
-          g[ii][J] = v;
-          acc[ii][J] = 0.0;
-        }
-      for (int c = 0; c < tb; ++c) {
-        __syncthreads();
-        stage2(Lt + yw_tri(ta, c) * TILE, false, Yt + yw_tri(tb, c) * TILE, false);
-        __syncthreads();
-        gemm_nt(acc);
-        if (a.Vq_logdet && ta == p && tb == p) {   // V_{c+1} = R_0 - sum_{c' <= c} ...
-          double vq[NIW][NJ];
-#pragma unroll
-          for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-            for (int J = 0; J < NJ; ++J) vq[ii][J] = g[ii][J] - acc[ii][J];
-          __syncthreads();
-          strip_to_lds(Xs, vq);
-          __syncthreads();
-          tile_inverse_from_Xs(nullptr, a.Vq_logdet + (size_t)item * p + c);
-        }
-      }
-#pragma unroll
-      for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-        for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-
-      if (tb < ta) {
-        store_tile(Yt + yw_tri(ta, tb) * TILE, g);
-        __syncthreads();
-        strip_to_lds(Xs, g);
-        stage2(nullptr, false, Dinv + (size_t)tb * TILE, true);
-        __syncthreads();
-#pragma unroll
-        for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-          for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-        gemm_nt(acc);
-        store_tile(Lt + yw_tri(ta, tb) * TILE, acc);
-      } else if (ta < p) {
-        __syncthreads();
-        strip_to_lds(Xs, g);
-        __syncthreads();
-        tile_inverse_from_Xs(Dinv + (size_t)ta * TILE, nullptr);
-      } else {
-        store_tile(a.V + (size_t)item * TILE, g);
-      }
-      __syncthreads();
-    }
   }
-
-  // ---- back substitution with the unit lower factor -----------------------------------------------
-  for (int tb = p - 1; tb >= 0; --tb) {
-    double g[NIW][NJ], acc[NIW][NJ];
-    const double* src = Lt + yw_tri(p, tb) * TILE;
+  __device__ __forceinline__ int row_of(int ii) const { return 4 * (wv * NT + ii) + i; }
+  __device__ __forceinline__ void load_tile(double (&v)[NIW][NJ], const double* src) const {
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) v[ii][J] = src[(size_t)row_of(ii) * MP + 16 * J + cc];
+  }
+  __device__ __forceinline__ void store_tile(double* dst, const double (&v)[NIW][NJ]) const {
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) dst[(size_t)row_of(ii) * MP + 16 * J + cc] = v[ii][J];
+  }
+  __device__ __forceinline__ void strip_to_lds(double* dst, const double (&v)[NIW][NJ]) const {
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) dst[row_of(ii) * S + 16 * J + cc] = v[ii][J];
+  }
+  // tile (ta, tb) of the augmented matrix, straight from the lag covariances
+  __device__ __forceinline__ void load_G(double (&g)[NIW][NJ], const double* R, int ta, int tb, int p) const {
 #pragma unroll
     for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
-        g[ii][J] = src[(size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc];
-        acc[ii][J] = 0.0;
+        const int row = row_of(ii), col = 16 * J + cc;
+        double v;
+        if (ta < p) v = R[(size_t)(ta - tb) * TILE + row * MP + col];
+        else if (tb < p) v = R[(size_t)(tb + 1) * TILE + col * MP + row];
+        else v = R[row * MP + col];
+        g[ii][J] = v;
       }
-    for (int c = tb + 1; c < p; ++c) {
-      __syncthreads();
-      stage2(Zt + (size_t)c * TILE, false, Lt + yw_tri(c, tb) * TILE, true);
-      __syncthreads();
-      gemm_nt(acc);
-    }
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-    store_tile(Zt + (size_t)tb * TILE, g);
-    double* ar = a.ar + (size_t)item * TILE * p;
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J)
-        ar[((size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc) * p + tb] = g[ii][J];
-    __syncthreads();
   }
-  if (wv == 0 && l == 0) a.info[item] = info;
+};
+
+struct YwPtrs {
+  const double* R;
+  double *Yt, *Lt, *Dinv, *Zt;
+};
+template <int MP>
+__device__ __forceinline__ YwPtrs yw_ptrs(const YwArgs& a, long long item) {
+  constexpr int TILE = MP * MP;
+  const int p = a.p;
+  double* ws = a.ws + (size_t)item * yw_ws_tiles_d(p) * TILE;
+  const long long ntri = yw_tri(p + 1, 0);
+  YwPtrs q;
+  q.R = a.R + (size_t)item * (p + 1) * TILE;
+  q.Yt = ws;
+  q.Lt = ws + ntri * TILE;
+  q.Dinv = ws + 2 * ntri * TILE;
+  q.Zt = q.Dinv + (size_t)p * TILE;
+  return q;
+}
+
+// The factorisation is launched tile column by tile column (and the back substitution pivot block by pivot
+// block): one workgroup per window cannot fill 256 CUs (599 windows per 10-minute dyad), one workgroup
+// per (window, tile) can.
+//
+// ---- diagonal tile (tb, tb):  D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ;  D^-1 (tb < p) or V (tb == p)
+template <int NT>
+__global__ void __launch_bounds__(256, 2) yw_diag_kernel(YwArgs a, int tb) {
+  using T = YwTile<NT>;
+  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
+  __shared__ double Xs[MP * S];
+  __shared__ double Ys[MP * S];
+  __shared__ double Pb[MP * 4];
+  __shared__ double Nb[MP * 4];
+  T t(Xs, Ys);
+  const long long item = blockIdx.x;
+  const int p = a.p;
+  const YwPtrs q = yw_ptrs<MP>(a, item);
+  int info = 0;
+  auto tile_inverse_from_Xs = [&](double* dinv_out, double* logdet_out) {
+    if (t.wv == 0) {
+      double m[4 * NT][NT];
+#pragma unroll
+      for (int I = 0; I < 4 * NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) m[I][J] = Xs[(4 * I + t.i) * S + 16 * J + t.cc];
+      double ld = 0.0;
+      spd_inverse_wave<NT>(m, Pb, Nb, info, ld, logdet_out != nullptr);
+      if (dinv_out) {
+#pragma unroll
+        for (int I = 0; I < 4 * NT; ++I)
+#pragma unroll
+          for (int J = 0; J < NT; ++J) dinv_out[(size_t)(4 * I + t.i) * MP + 16 * J + t.cc] = m[I][J];
+      }
+      if (logdet_out && t.l == 0) *logdet_out = ld;
+    }
+  };
+  double g[NIW][NJ], acc[NIW][NJ];
+  t.load_G(g, q.R, tb, tb, p);
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
+  for (int c = 0; c < tb; ++c) {
+    __syncthreads();
+    t.stage2(q.Lt + yw_tri(tb, c) * TILE, false, q.Yt + yw_tri(tb, c) * TILE, false);
+    __syncthreads();
+    t.gemm_nt(acc);
+    if (a.Vq_logdet && tb == p) {   // V_{c+1} = R_0 - sum_{c' <= c} ... : residual covariance of order c+1
+      double vq[NIW][NJ];
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) vq[ii][J] = g[ii][J] - acc[ii][J];
+      __syncthreads();
+      t.strip_to_lds(Xs, vq);
+      __syncthreads();
+      tile_inverse_from_Xs(nullptr, a.Vq_logdet + (size_t)item * p + c);
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+  if (tb < p) {
+    __syncthreads();
+    t.strip_to_lds(Xs, g);
+    __syncthreads();
+    tile_inverse_from_Xs(q.Dinv + (size_t)tb * TILE, nullptr);
+    if (t.wv == 0 && t.l == 0 && info != 0) atomicCAS(&a.info[item], 0, tb * MP + info);
+  } else {
+    t.store_tile(a.V + (size_t)item * TILE, g);
+  }
+}
+
+// ---- off-diagonal tiles (ta, tb), ta = tb+1 .. p:  Y = G - sum_c Lt[ta][c] Y[tb][c]^T ;  Lt = Y D_tb^-1
+template <int NT>
+__global__ void __launch_bounds__(256, 2) yw_col_kernel(YwArgs a, int tb) {
+  using T = YwTile<NT>;
+  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
+  __shared__ double Xs[MP * S];
+  __shared__ double Ys[MP * S];
+  T t(Xs, Ys);
+  const long long item = blockIdx.x;
+  const int ta = tb + 1 + blockIdx.y;
+  const int p = a.p;
+  const YwPtrs q = yw_ptrs<MP>(a, item);
+  double g[NIW][NJ], acc[NIW][NJ];
+  t.load_G(g, q.R, ta, tb, p);
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
+  for (int c = 0; c < tb; ++c) {
+    __syncthreads();
+    t.stage2(q.Lt + yw_tri(ta, c) * TILE, false, q.Yt + yw_tri(tb, c) * TILE, false);
+    __syncthreads();
+    t.gemm_nt(acc);
+  }
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+  t.store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
+  __syncthreads();
+  t.strip_to_lds(Xs, g);
+  t.stage2(nullptr, false, q.Dinv + (size_t)tb * TILE, true);
+  __syncthreads();
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
+  t.gemm_nt(acc);
+  t.store_tile(q.Lt + yw_tri(ta, tb) * TILE, acc);
+  if (ta == p) t.store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
+}
+
+// ---- back substitution with the unit lower factor, pivot block c:  Z[b] -= Z[c] Lt[c][b]  for b < c
+template <int NT>
+__global__ void __launch_bounds__(256, 2) yw_back_kernel(YwArgs a, int c) {
+  using T = YwTile<NT>;
+  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
+  __shared__ double Xs[MP * S];
+  __shared__ double Ys[MP * S];
+  T t(Xs, Ys);
+  const long long item = blockIdx.x;
+  const int b = blockIdx.y;
+  const YwPtrs q = yw_ptrs<MP>(a, item);
+  double z[NIW][NJ], acc[NIW][NJ];
+  t.load_tile(z, q.Zt + (size_t)b * TILE);
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
+  t.stage2(q.Zt + (size_t)c * TILE, false, q.Lt + yw_tri(c, b) * TILE, true);
+  __syncthreads();
+  t.gemm_nt(acc);
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int J = 0; J < NJ; ++J) z[ii][J] -= acc[ii][J];
+  t.store_tile(q.Zt + (size_t)b * TILE, z);
+}
+
+// ---- ar[item][row][col][k] = Z[k][row][col]  (lag fastest: the reference's (m, m, p) layout)
+template <int NT>
+__global__ void __launch_bounds__(256) yw_emit_kernel(YwArgs a) {
+  constexpr int MP = 16 * NT, TILE = MP * MP;
+  const long long item = blockIdx.x;
+  const int p = a.p;
+  const YwPtrs q = yw_ptrs<MP>(a, item);
+  double* ar = a.ar + (size_t)item * TILE * p;
+  for (int e = threadIdx.x; e < TILE; e += 256)
+    for (int k = 0; k < p; ++k) ar[(size_t)e * p + k] = q.Zt[(size_t)k * TILE + e];
+}
+
+template <int NT>
+static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
+  const int p = a.p;
+  const unsigned n = (unsigned)a.n_items;
+  (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
+  for (int tb = 0; tb <= p; ++tb) {
+    hipLaunchKernelGGL(yw_diag_kernel<NT>, dim3(n), dim3(256), 0, st, a, tb);
+    if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(n, p - tb), dim3(256), 0, st, a, tb);
+  }
+  for (int c = p - 1; c >= 1; --c) hipLaunchKernelGGL(yw_back_kernel<NT>, dim3(n, c), dim3(256), 0, st, a, c);
+  hipLaunchKernelGGL(yw_emit_kernel<NT>, dim3(n), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
 }
 
 int launch_yw(const YwArgs& a, int m_pad, hipStream_t st) {
   if (a.n_items == 0) return 0;
-  const dim3 grid((unsigned)a.n_items), block(256);
   switch (m_pad) {
-    case 16: hipLaunchKernelGGL(yw_kernel<1>, grid, block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL(yw_kernel<2>, grid, block, 0, st, a); break;
-    case 48: hipLaunchKernelGGL(yw_kernel<3>, grid, block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL(yw_kernel<4>, grid, block, 0, st, a); break;
+    case 16: return launch_yw_nt<1>(a, st);
+    case 32: return launch_yw_nt<2>(a, st);
+    case 48: return launch_yw_nt<3>(a, st);
+    case 64: return launch_yw_nt<4>(a, st);
     default: return -1;
   }
-  return (int)hipGetLastError();
 }
 
 }  // namespace hmv
