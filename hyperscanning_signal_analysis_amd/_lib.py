@@ -33,7 +33,7 @@ SIGNATURES = {
     "hmv_sliding_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p,
-                                      c_void_p]),
+                                      c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -145,7 +145,8 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
                           const int64_t* item_start, int64_t n_items, int m, int n, int p,
                           const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
-                          int64_t chunk, double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream) {
+                          int64_t chunk, double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream,
+                          void* aux_stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
@@ -153,36 +154,60 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   if (!x || !item_rec || !item_start || !freqs || !ffdtf || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
   const SlidingWs w = sliding_layout(chunk, mp, p, F);
-  if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
-  char* base = static_cast<char*>(workspace);
-  double* R = reinterpret_cast<double*>(base + w.off_R);
-  double* ws = reinterpret_cast<double*>(base + w.off_ws);
-  double* ar = reinterpret_cast<double*>(base + w.off_ar);
-  double* V = reinterpret_cast<double*>(base + w.off_V);
-  double* P = reinterpret_cast<double*>(base + w.off_P);
-  double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
-  double* den = reinterpret_cast<double*>(base + w.off_den);
-  double* tw = reinterpret_cast<double*>(base + w.off_tw);
-  int rc = hmv_twiddles_f64(freqs, F, fs, p, tw, stream);
-  if (rc) return rc;
+  const int lanes = (aux_stream && aux_stream != stream && n_items > chunk) ? 2 : 1;
+  if ((int64_t)(w.total * lanes) > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
+  hipStream_t st[2] = {S(stream), S(aux_stream)};
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  if (lanes == 2) {
+    // fork: the auxiliary stream starts after everything already queued on the caller's stream
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
+      return fail(-8, "hmv_sliding_ffdtf_f64: cannot create fork/join events");
+    (void)hipEventRecord(ev_fork, st[0]);
+    (void)hipStreamWaitEvent(st[1], ev_fork, 0);
+  }
+  int rc = 0;
   const size_t t = (size_t)mp * mp;
-  for (int64_t i0 = 0; i0 < n_items; i0 += chunk) {
+  const int64_t n_chunks = (n_items + chunk - 1) / chunk;
+  for (int64_t ci = 0; ci < n_chunks && rc == 0; ++ci) {
+    const int lane = (int)(ci % lanes);
+    void* s = st[lane];
+    char* base = static_cast<char*>(workspace) + (size_t)lane * w.total;
+    double* R = reinterpret_cast<double*>(base + w.off_R);
+    double* ws = reinterpret_cast<double*>(base + w.off_ws);
+    double* ar = reinterpret_cast<double*>(base + w.off_ar);
+    double* V = reinterpret_cast<double*>(base + w.off_V);
+    double* P = reinterpret_cast<double*>(base + w.off_P);
+    double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+    double* den = reinterpret_cast<double*>(base + w.off_den);
+    double* tw = reinterpret_cast<double*>(base + w.off_tw);
+    if (ci < lanes) {                       // each lane keeps its own twiddle table: no cross-stream edge
+      rc = hmv_twiddles_f64(freqs, F, fs, p, tw, s);
+      if (rc) break;
+    }
+    const int64_t i0 = ci * chunk;
     const int64_t c = (n_items - i0 < chunk) ? (n_items - i0) : chunk;
     double* ar_c = ar_out ? ar_out + (size_t)i0 * t * p : ar;
     double* V_c = V_out ? V_out + (size_t)i0 * t : V;
-    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, stream);
-    if (rc) return rc;
-    rc = hmv_yw_solve_f64(R, c, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, stream);
-    if (rc) return rc;
-    const bool last = (i0 + chunk >= n_items);
-    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), S(stream));
-    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, stream);
-    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), S(stream));
-    if (rc) return rc;
-    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, stream);
-    if (rc) return rc;
+    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, s);
+    if (rc) break;
+    rc = hmv_yw_solve_f64(R, c, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, s);
+    if (rc) break;
+    const bool last = (ci == n_chunks - 1);
+    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), S(s));
+    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, s);
+    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), S(s));
+    if (rc) break;
+    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, s);
   }
-  return 0;
+  if (lanes == 2) {
+    // join: the caller's stream continues only after the auxiliary stream has drained
+    (void)hipEventRecord(ev_join, st[1]);
+    (void)hipStreamWaitEvent(st[0], ev_join, 0);
+    (void)hipEventDestroy(ev_fork);
+    (void)hipEventDestroy(ev_join);
+  }
+  return rc;
 }
 
 }  // extern "C"

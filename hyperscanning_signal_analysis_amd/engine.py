@@ -38,6 +38,7 @@ class Engine:
         self.pivot_tau = float(pivot_tau)
         self.max_workspace_bytes = int(max_workspace_bytes)
         self._ws = None
+        self._aux = None        # second HIP stream for chunk overlap in the fused path
 
     # ------------------------------------------------------------------ helpers
     def stream(self):
@@ -153,15 +154,24 @@ class Engine:
         return S
 
     # ------------------------------------------------------------------ fused sliding-window path
-    def sliding_chunk(self, n_items: int, m: int, p: int, F: int) -> int:
+    def sliding_chunk(self, n_items: int, m: int, p: int, F: int, lanes: int = 1) -> int:
         per_item = int(self.lib.hmv_sliding_workspace_bytes(1, m, p, F))
-        return max(1, min(n_items, self.max_workspace_bytes // max(per_item, 1)))
+        cap = max(1, self.max_workspace_bytes // max(per_item * lanes, 1))
+        want = -(-n_items // lanes)            # two lanes: at least two chunks so they can overlap
+        return max(1, min(want, cap))
+
+    def aux_stream(self):
+        if self._aux is None:
+            self._aux = torch.cuda.Stream(device=self.device)
+        return self._aux
 
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
-                      check: bool = True, chunk: int | None = None, k3_events=None):
+                      check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = False):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
+        overlap: alternate chunks between the current stream and a second stream (see include/hypermvar.h);
+        measured gain on the north-star workload is small (~2 %), so it is off by default.
         k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
         have been recorded once) which the library records around the dominant kernel.
         """
@@ -172,9 +182,11 @@ class Engine:
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
-        chunk = self.sliding_chunk(n_items, m, p, F) if chunk is None else int(chunk)
-        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F))
+        lanes = 2 if (overlap and n_items >= 8) else 1
+        chunk = self.sliding_chunk(n_items, m, p, F, lanes) if chunk is None else int(chunk)
+        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F)) * lanes
         ws = self._workspace(nbytes)
+        aux = self.aux_stream().cuda_stream if lanes == 2 else 0
         if out is None:
             out = self.empty(n_items, m, m, F)
         ar = self.empty(n_items, mp, mp, p) if return_ar else None
@@ -186,7 +198,7 @@ class Engine:
                 x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
                 m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
                 info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau,
-                k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream())
+                k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
         _lib.check(rc, "hmv_sliding_ffdtf_f64")
         if check:
             self.raise_on_info(info_yw, "yw")

@@ -224,3 +224,19 @@ def test_northstar_full_size_properties():
     for k in (0, 29, nw - 1):
         ref = O.full_freq_dtf(x[:, 500 * k:500 * k + w], freqs, fs, p)
         assert_parity(ff[k].cpu().numpy(), ref)
+
+
+def test_two_stream_overlap_is_bit_identical():
+    """Chunks alternating between two HIP streams (fork/join inside the fused C call) give the same bits."""
+    eng = default_engine()
+    x = synthetic_var_dyad(5, T=12_000)
+    freqs = northstar_freqs(64)
+    xd = eng.to_device(x[None])
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    pos, w = window_positions(12_000, 23, 1000)
+    rec, st = window_items(1, pos, eng.device)
+    a = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=False)
+    b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=6, overlap=True)
+    c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
