@@ -48,6 +48,21 @@ namespace hmv {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
 
+// Phase stamps for the diagnostic build (-DHMV_STAMP, `make stamp`): shares of a wave's life, not its length.
+#ifdef HMV_STAMP
+#define HMV_T(idx)                                                                     \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    unsigned long long t_;                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    tsum[idx] += t_ - tlast;                                                           \
+    tlast = t_;                                                                        \
+  } while (0)
+#else
+#define HMV_T(idx) do { } while (0)
+#endif
+
 template <int NT>
 struct TfLds {
   static constexpr int MP = 16 * NT;
@@ -66,7 +81,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   using L = TfLds<NT>;
   __shared__ double2 smem[L::TOTAL];
   __shared__ int s_orig[MP];
-  __shared__ int s_swp[2][4];
+  __shared__ __attribute__((aligned(16))) int s_swp[2][4];
   __shared__ int s_info;
 
   const int l = lane_id();
@@ -89,6 +104,10 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   double* rsum = reinterpret_cast<double*>(Srow + L::SROW + L::SWAPB);
 
   double re[NI], im[NI];
+#ifdef HMV_STAMP
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
 
   // ---------------------------------------------------------------- A(f), this wave's 16 columns
   {
@@ -164,12 +183,14 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     if (l == 0) s_info = 0;
   }
   const double tau = a.tau;
+  HMV_T(0);
 
   // ---------------------------------------------------------------- blocked Gauss-Jordan
   static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
     constexpr int ws = s >> 2, q = s & 3;
     double2* Ncur = Nbuf + (s & 1) * L::NBUF;
+    HMV_T(5);
 
     if (w == ws) {
       // ---- 1. panel -> LDS -> lane-per-row, four pivot steps (this wave only).  The factorisation is the
@@ -181,21 +202,17 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         for (int I = 0; I < NI; ++I) Pbuf[(4 * I + i) * 5 + (cc & 3)] = make_double2(re[I], im[I]);
       }
       HMV_LDS_FENCE();
-      double xr[4], xi[4];
+      double2 x[4];     // (re, im) adjacent: LDS transfers need no register shuffling
       {
         const int r = (l < MP) ? l : 0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const double2 v = Pbuf[r * 5 + jj];
-          xr[jj] = v.x;
-          xi[jj] = v.y;
-        }
+        for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
       }
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int col = 4 * s + jj;
         const bool valid = (l >= col) && (l < MP);
-        const double cand = valid ? (__builtin_fabs(xr[jj]) + __builtin_fabs(xi[jj])) : -1.0;
+        const double cand = valid ? (__builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y)) : -1.0;
         // arg-max over the not-yet-pivoted rows: float-rounded magnitude as a 32-bit key (monotonic for
         // non-negative floats), DPP max, lowest lane holding the maximum.
         const unsigned key = valid ? __float_as_uint((float)cand) : 0u;
@@ -205,47 +222,44 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
           const double vmax = readlane_f64(cand, rstar), dc = readlane_f64(cand, col);
           if (dc >= tau * vmax) rstar = col;
         }
-        // pivot row and displaced row -> LDS -> broadcast to every lane (no v_readlane chains)
+        // pivot element by v_readlane (the reciprocal chain starts at once); the pivot row -- and, on an
+        // interchange, the displaced row -- go through LDS and are broadcast to every lane
+        const double pr = readlane_f64(x[jj].x, rstar), pi = readlane_f64(x[jj].y, rstar);
         if (l == rstar) {
 #pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = make_double2(xr[j2], xi[j2]);
+          for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
         }
-        if (l == col) {
+        if (rstar != col) {          // uniform
+          if (l == col) {
 #pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = make_double2(xr[j2], xi[j2]);
-        }
-        if (l == 0) {
-          s_swp[s & 1][jj] = rstar;
-          if (rstar != col) {
+            for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
+          }
+          if (l == 0) {
             const int oc = s_orig[col], orr = s_orig[rstar];
             s_orig[col] = orr;
             s_orig[rstar] = oc;
           }
         }
-        HMV_LDS_FENCE();
-        double pvr[4], pvi[4];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const double2 pv = Srow[j2];
-          pvr[j2] = pv.x;
-          pvi[j2] = pv.y;
-        }
-        if (rstar != col) {          // uniform: the lane that held the pivot row takes the displaced row
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) {
-            const double2 cv = Srow[4 + j2];
-            xr[j2] = (l == rstar) ? cv.x : xr[j2];
-            xi[j2] = (l == rstar) ? cv.y : xi[j2];
-          }
-        }
-        HMV_LDS_FENCE();
-        const double pr = pvr[jj], pi = pvi[jj];
+        if (l == 0) s_swp[s & 1][jj] = rstar;
         const double dd = __builtin_fma(pr, pr, pi * pi);
         if (!(dd > 0.0) && l == 0 && s_info == 0) s_info = col + 1;
         double invd = __builtin_amdgcn_rcp(dd);                    // v_rcp_f64 seed + 2 Newton steps
         invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
         invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
         const double ivr = pr * invd, ivi = -pi * invd;
+        HMV_LDS_FENCE();
+        double2 pv[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) pv[j2] = Srow[j2];
+        if (rstar != col) {          // uniform: the lane that held the pivot row takes the displaced row
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) {
+            const double2 cv = Srow[4 + j2];
+            x[j2].x = (l == rstar) ? cv.x : x[j2].x;
+            x[j2].y = (l == rstar) ? cv.y : x[j2].y;
+          }
+        }
+        HMV_LDS_FENCE();
         double qr[4], qi[4];
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
@@ -253,34 +267,40 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
             qr[j2] = ivr;
             qi[j2] = ivi;
           } else {
-            qr[j2] = pvr[j2] * ivr - pvi[j2] * ivi;
-            qi[j2] = pvr[j2] * ivi + pvi[j2] * ivr;
+            qr[j2] = __builtin_fma(-pv[j2].y, ivi, pv[j2].x * ivr);
+            qi[j2] = __builtin_fma(pv[j2].y, ivr, pv[j2].x * ivi);
           }
         }
-        const double fr = xr[jj], fi = xi[jj];
+        // x <- x - f q for every row but the pivot row, which becomes q itself (column jj: in-place
+        // inverse trick, x_jj is treated as 0).  Pure FMA chains: 4 per complex element.
+        const double fr = x[jj].x, fi = x[jj].y;
         const bool isp = (l == col);
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
-          const double tr = fr * qr[j2] - fi * qi[j2], ti = fr * qi[j2] + fi * qr[j2];
-          const double nr = (j2 == jj) ? -tr : xr[j2] - tr;
-          const double ni = (j2 == jj) ? -ti : xi[j2] - ti;
-          xr[j2] = isp ? qr[j2] : nr;
-          xi[j2] = isp ? qi[j2] : ni;
+          const double br = (j2 == jj) ? 0.0 : x[j2].x, bi = (j2 == jj) ? 0.0 : x[j2].y;
+          const double nr = __builtin_fma(fi, qi[j2], __builtin_fma(-fr, qr[j2], br));
+          const double ni = __builtin_fma(-fi, qr[j2], __builtin_fma(-fr, qi[j2], bi));
+          x[j2].x = isp ? qr[j2] : nr;
+          x[j2].y = isp ? qi[j2] : ni;
         }
       }
       if (l < MP) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) Ncur[l * 4 + jj] = make_double2(xr[jj], xi[jj]);
+        for (int jj = 0; jj < 4; ++jj) Ncur[l * 4 + jj] = x[jj];
       }
       __builtin_amdgcn_s_setprio(0);
+      HMV_T(1);
     }
     __syncthreads();   // ---- 2. N, the interchange list and orig[] are visible to every wave
 
+    HMV_T(2);
     // ---- 3a. pending row interchanges on this wave's columns
+    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[s & 1][0]);   // one LDS round trip, not four
+    const int swr[4] = {uni(swv.x), uni(swv.y), uni(swv.z), uni(swv.w)};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * s + jj;
-      const int rstar = uni(s_swp[s & 1][jj]);
+      const int rstar = swr[jj];
       if (rstar != col) {
         const int Ist = rstar >> 2, ist = rstar & 3;
         if (i == jj) swapb[cc] = make_double2(re[s], im[s]);
@@ -306,22 +326,34 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         HMV_LDS_FENCE();
       }
     }
+    HMV_T(3);
     // ---- 3b. rank-4 update of this wave's column group on the matrix pipe
     const double ur = re[s], ui = im[s];
-    double2 nvn = Ncur[(l & 3) * 4 + (l >> 4)];
-    static_for<NI>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int I = decltype(ic)::value;
-      const double2 nv = nvn;
-      if (I + 1 < NI) nvn = Ncur[(4 * (I + 1) + (l & 3)) * 4 + (l >> 4)];
-      double nr = nv.x;
-      const double ni = nv.y;
-      if (I == s) nr -= ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
-      const double nni = -ni;
-      re[I] = mfma4(nr, ur, re[I]);
-      im[I] = mfma4(nr, ui, im[I]);
-      re[I] = mfma4(nni, ui, re[I]);
-      im[I] = mfma4(ni, ur, im[I]);
+    // Two row blocks per iteration: the second MFMA on an accumulator is issued four MFMAs after the first
+    // (dependent-accumulator latency), and the A operands of the next pair are fetched from LDS before
+    // this pair's MFMAs are issued.
+    double2 nva = Ncur[(l & 3) * 4 + (l >> 4)];
+    double2 nvb = Ncur[(4 + (l & 3)) * 4 + (l >> 4)];
+    static_for<NI / 2>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int I = 2 * decltype(ic)::value;
+      const double2 na = nva, nb = nvb;
+      if (I + 2 < NI) {
+        nva = Ncur[(4 * (I + 2) + (l & 3)) * 4 + (l >> 4)];
+        nvb = Ncur[(4 * (I + 3) + (l & 3)) * 4 + (l >> 4)];
+      }
+      const double dlt = ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
+      const double ar_ = (I == s) ? na.x - dlt : na.x, ai_ = na.y, an_ = -na.y;
+      const double br_ = (I + 1 == s) ? nb.x - dlt : nb.x, bi_ = nb.y, bn_ = -nb.y;
+      re[I] = mfma4(ar_, ur, re[I]);
+      im[I] = mfma4(ar_, ui, im[I]);
+      re[I + 1] = mfma4(br_, ur, re[I + 1]);
+      im[I + 1] = mfma4(br_, ui, im[I + 1]);
+      re[I] = mfma4(an_, ui, re[I]);
+      im[I] = mfma4(ai_, ur, im[I]);
+      re[I + 1] = mfma4(bn_, ui, re[I + 1]);
+      im[I + 1] = mfma4(bi_, ur, im[I + 1]);
     });
+    HMV_T(4);
     // ---- 4. panel columns <- N (owner wave)
     if (w == ws && (cc >> 2) == q) {
 #pragma unroll
@@ -333,6 +365,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     }
   });
 
+  HMV_T(5);
   // ---------------------------------------------------------------- outputs
   // Lane coordinates are re-derived from an opaque lane id: reusing `i` would keep the 15 row indices
   // 4I+i of the prologue alive across the whole sweep (they were spilled to scratch: 2.5 GB per launch).
@@ -365,7 +398,14 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       a.rowsum[(size_t)gw * MP + lo] = t;
     }
   }
+#ifdef HMV_STAMP
+  HMV_T(6);
+  if (a.stamps && lo == 0) {
+    for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
+  }
+#endif
 }
+
 
 // ---------------------------------------------------------------- twiddles
 // tw[f][k] = exp(-(k+1) * 2*pi*1j * freqs[f] / fs), same operation order as mtmvar.py:153.

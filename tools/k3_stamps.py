@@ -1,6 +1,6 @@
-"""Diagnostic: phase shares of the K3 kernel from the -DHMV_STAMP build (make -C csrc stamp).
-Phases: 0 A(f) build | 1 panel->LDS->lane-per-row | 2 pivot steps | 3 N write + row swaps |
-        4 operand reads + MFMA update | 5 panel write-back | 6 outputs."""
+"""Diagnostic: per-wave phase shares of the K3 kernel from the -DHMV_STAMP build (make -C csrc stamp).
+Phases: 0 A(f) build | 1 panel factorisation (owner wave) | 2 barrier wait | 3 row interchanges |
+        4 operand reads + MFMA update | 5 panel write-back + loop glue | 6 outputs."""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +23,7 @@ ar, V, _, info = eng.yw_solve(R, m)
 tw = eng.twiddles(0.5 * np.arange(1, F + 1), 500.0, p)
 P = torch.empty(n_items, F, 64, 64, dtype=torch.float64, device=dev); rs = torch.empty(n_items, F, 64, dtype=torch.float64, device=dev)
 inf = torch.zeros(n_items * F, dtype=torch.int32, device=dev)
-stamps = torch.zeros(n_items * F, 8, dtype=torch.int64, device=dev)
+stamps = torch.zeros(n_items * F * 4, 8, dtype=torch.int64, device=dev)
 lib.hmv_debug_set_tf_stamps(stamps.data_ptr())
 for rep in range(2):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,7 +34,7 @@ for rep in range(2):
 print("stamped kernel ms:", e0.elapsed_time(e1), "(do not quote: stamps serialise)")
 s = stamps.cpu().numpy().astype(np.float64)
 tot = s.sum(axis=1)
-names = ["A(f) build", "panel extract", "pivot steps", "N write+swaps", "MFMA update", "panel writeback", "outputs", "-"]
-print(f"cycles per matrix: median {np.median(tot):.0f}  mean {tot.mean():.0f}")
+names = ["A(f) build", "panel factor", "barrier wait", "interchanges", "MFMA update", "writeback+glue", "outputs", "-"]
+print(f"cycles per wave life: median {np.median(tot):.0f}  mean {tot.mean():.0f}")
 for k in range(7):
     print(f"  {names[k]:16s} median {np.median(s[:, k]):9.0f} cyc  share {s[:, k].sum() / tot.sum() * 100:5.1f} %")
