@@ -46,7 +46,7 @@ FLOP_K3_WINDOW = FLOP_AF + FLOP_INV + 3.0 * 64 * 64 * 256                    # 5
 PEAK_F64_TFLOPS = 78.6          # MI355X spec, vector = matrix f64 (measured ceiling ~65: DESIGN.md)
 
 
-def cpu_baseline(x_host, positions, w, p, freqs, fs, budget_s=15.0, max_windows=64):
+def cpu_baseline(x_host, positions, w, p, freqs, fs, budget_s=15.0, max_windows=256):
     """Reference-style (per-frequency Python loop) NumPy port timed on this host, 1 BLAS thread."""
     from oracle import mvar_oracle as O      # the ONLY place bench.py touches oracle/
     try:
@@ -64,7 +64,7 @@ def cpu_baseline(x_host, positions, w, p, freqs, fs, budget_s=15.0, max_windows=
                 break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "windows/s", "cores": 1, "kind": "port",
-            "sample": f"first {done} of the 599 windows of dyad 0, oracle.full_freq_dtf_loop "
+            "sample": f"first {done} of the {len(positions)} windows of dyad 0, oracle.full_freq_dtf_loop "
                       f"(reference loop structure, NumPy/OpenBLAS 1 thread), {dt:.1f} s"}
 
 

@@ -288,14 +288,20 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) Ncur[l * 4 + jj] = x[jj];
       }
-      __builtin_amdgcn_s_setprio(0);
       HMV_T(1);
     }
+    // The wave that factors the NEXT panel stays at high priority through its own update as well: panel
+    // factorisation -> update of the owner's columns -> next factorisation is the workgroup's critical path.
+    if (s + 1 < NSTEP && w == ((s + 1) >> 2)) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
     __syncthreads();   // ---- 2. N, the interchange list and orig[] are visible to every wave
 
     HMV_T(2);
     // ---- 3a. pending row interchanges on this wave's columns
-    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[s & 1][0]);   // one LDS round trip, not four
+    // first A operands and the interchange list are fetched together: one LDS round trip after the barrier
+    double2 nva = Ncur[(l & 3) * 4 + (l >> 4)];
+    double2 nvb = Ncur[(4 + (l & 3)) * 4 + (l >> 4)];
+    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[s & 1][0]);
     const int swr[4] = {uni(swv.x), uni(swv.y), uni(swv.z), uni(swv.w)};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -332,8 +338,6 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     // Two row blocks per iteration: the second MFMA on an accumulator is issued four MFMAs after the first
     // (dependent-accumulator latency), and the A operands of the next pair are fetched from LDS before
     // this pair's MFMAs are issued.
-    double2 nva = Ncur[(l & 3) * 4 + (l >> 4)];
-    double2 nvb = Ncur[(4 + (l & 3)) * 4 + (l >> 4)];
     static_for<NI / 2>([&](auto ic) __attribute__((always_inline)) {
       constexpr int I = 2 * decltype(ic)::value;
       const double2 na = nva, nb = nvb;
