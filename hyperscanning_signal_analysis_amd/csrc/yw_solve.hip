@@ -115,6 +115,96 @@ __device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double
   }
 }
 
+// Cooperative inverse of the symmetric positive definite MP x MP tile stored row-major (stride S) in LDS
+// `Xs`, by the whole workgroup (same scheme as K3, real arithmetic, no pivoting): wave w < NT holds columns
+// 16w..16w+15 in the D layout; the wave that owns the 4 panel columns of block step s factors them in a
+// lane-per-row layout (pivots by v_readlane, Newton reciprocal), publishes N = M'[:, S] through LDS, and
+// after one barrier every wave runs its 4*NT MFMAs of the rank-4 update.  Must be called by all 256 threads.
+// dinv_out (global, may be null): the inverse;  logdet_out (global, may be null): log det of the tile.
+template <int NT, int S>
+__device__ __forceinline__ void spd_inverse_coop(const double* Xs, double* Pb, double* Nb2, int* s_info,
+                                                 double* s_ld, double* dinv_out, double* logdet_out, int info_base) {
+  constexpr int MP = 16 * NT, NI = 4 * NT, NSTEP = MP / 4;
+  const int l = lane_id();
+  const int w = uni(threadIdx.x >> 6);
+  const int i = l >> 4, cc = l & 15;
+  const bool active = (w < NT);
+  double m[NI];
+  if (active) {
+#pragma unroll
+    for (int I = 0; I < NI; ++I) m[I] = Xs[(4 * I + i) * S + 16 * w + cc];
+  }
+  double mypiv = 1.0;
+  static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int ws = s >> 2, q = s & 3;
+    double* Nb = Nb2 + (s & 1) * MP * 4;
+    if (w == ws) {
+      if ((cc >> 2) == q) {
+#pragma unroll
+        for (int I = 0; I < NI; ++I) Pb[(4 * I + i) * 4 + (cc & 3)] = m[I];
+      }
+      HMV_WAVE_SYNC();
+      double x[4];
+      {
+        const int r = (l < MP) ? l : 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) x[jj] = Pb[r * 4 + jj];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int col = 4 * s + jj;
+        const double piv = readlane_f64(x[jj], col);
+        if (!(piv > 0.0) && l == 0 && *s_info == 0) *s_info = info_base + col + 1;
+        mypiv = (l == col) ? piv : mypiv;
+        double inv = __builtin_amdgcn_rcp(piv);                  // v_rcp_f64 seed + 2 Newton steps
+        inv = __builtin_fma(__builtin_fma(-piv, inv, 1.0), inv, inv);
+        inv = __builtin_fma(__builtin_fma(-piv, inv, 1.0), inv, inv);
+        double qv[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) qv[j2] = (j2 == jj) ? inv : readlane_f64(x[j2], col) * inv;
+        const double f = x[jj];
+        const bool isp = (l == col);
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          const double base = (j2 == jj) ? 0.0 : x[j2];
+          const double nr = __builtin_fma(-f, qv[j2], base);
+          x[j2] = isp ? qv[j2] : nr;
+        }
+      }
+      if (l < MP) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Nb[l * 4 + jj] = x[jj];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const double u = m[s];
+#pragma unroll
+      for (int I = 0; I < NI; ++I) {
+        double nv = Nb[(4 * I + (l & 3)) * 4 + (l >> 4)];
+        if (I == s) nv -= ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
+        m[I] = mfma4(nv, u, m[I]);
+      }
+      if (w == ws && (cc >> 2) == q) {
+#pragma unroll
+        for (int I = 0; I < NI; ++I) m[I] = Nb[(4 * I + i) * 4 + (cc & 3)];
+      }
+    }
+  });
+  if (dinv_out && active) {
+#pragma unroll
+    for (int I = 0; I < NI; ++I) dinv_out[(size_t)(4 * I + i) * MP + 16 * w + cc] = m[I];
+  }
+  if (logdet_out) {          // pivots live on lane `col` of the wave that factored column `col`
+    double v = row16_sum_dpp(log(mypiv));
+    v = readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
+    if (l == 0) s_ld[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *logdet_out = ((s_ld[0] + s_ld[1]) + s_ld[2]) + s_ld[3];
+  }
+}
+
 // Shared pieces of the three kernels: tile staging, the MP^3 tile product, tile I/O in the D layout.
 template <int NT>
 struct YwTile {
@@ -230,30 +320,14 @@ __global__ void __launch_bounds__(256, 2) yw_diag_kernel(YwArgs a, int tb) {
   __shared__ double Xs[MP * S];
   __shared__ double Ys[MP * S];
   __shared__ double Pb[MP * 4];
-  __shared__ double Nb[MP * 4];
+  __shared__ double Nb[2 * MP * 4];
   T t(Xs, Ys);
   const long long item = blockIdx.x;
   const int p = a.p;
   const YwPtrs q = yw_ptrs<MP>(a, item);
-  int info = 0;
-  auto tile_inverse_from_Xs = [&](double* dinv_out, double* logdet_out) {
-    if (t.wv == 0) {
-      double m[4 * NT][NT];
-#pragma unroll
-      for (int I = 0; I < 4 * NT; ++I)
-#pragma unroll
-        for (int J = 0; J < NT; ++J) m[I][J] = Xs[(4 * I + t.i) * S + 16 * J + t.cc];
-      double ld = 0.0;
-      spd_inverse_wave<NT>(m, Pb, Nb, info, ld, logdet_out != nullptr);
-      if (dinv_out) {
-#pragma unroll
-        for (int I = 0; I < 4 * NT; ++I)
-#pragma unroll
-          for (int J = 0; J < NT; ++J) dinv_out[(size_t)(4 * I + t.i) * MP + 16 * J + t.cc] = m[I][J];
-      }
-      if (logdet_out && t.l == 0) *logdet_out = ld;
-    }
-  };
+  __shared__ int s_info;
+  __shared__ double s_ld[4];
+  if (threadIdx.x == 0) s_info = 0;
   double g[NIW][NJ], acc[NIW][NJ];
   t.load_G(g, q.R, tb, tb, p);
 #pragma unroll
@@ -274,7 +348,7 @@ __global__ void __launch_bounds__(256, 2) yw_diag_kernel(YwArgs a, int tb) {
       __syncthreads();
       t.strip_to_lds(Xs, vq);
       __syncthreads();
-      tile_inverse_from_Xs(nullptr, a.Vq_logdet + (size_t)item * p + c);
+      spd_inverse_coop<NT, S>(Xs, Pb, Nb, &s_info, s_ld, nullptr, a.Vq_logdet + (size_t)item * p + c, tb * MP);
     }
   }
 #pragma unroll
@@ -285,8 +359,9 @@ __global__ void __launch_bounds__(256, 2) yw_diag_kernel(YwArgs a, int tb) {
     __syncthreads();
     t.strip_to_lds(Xs, g);
     __syncthreads();
-    tile_inverse_from_Xs(q.Dinv + (size_t)tb * TILE, nullptr);
-    if (t.wv == 0 && t.l == 0 && info != 0) atomicCAS(&a.info[item], 0, tb * MP + info);
+    spd_inverse_coop<NT, S>(Xs, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_info != 0) atomicCAS(&a.info[item], 0, s_info);
   } else {
     t.store_tile(a.V + (size_t)item * TILE, g);
   }
