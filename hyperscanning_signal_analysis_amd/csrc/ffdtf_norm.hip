@@ -24,14 +24,17 @@ __global__ void __launch_bounds__(64) den_kernel(const double* rowsum, double* d
   den[(size_t)item * m_pad + i] = acc;
 }
 
-// grid: (ceil(F/64) * n_items, m); block 256
+// grid: ceil(F/64) * n_items * m; block 256
 __global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
   __shared__ double tile[64][65];
   const int MP = a.m_pad, m = a.m, F = a.F;
   const int nft = (F + 63) / 64;
-  const long long item = blockIdx.x / nft;
-  const int f0 = (blockIdx.x % nft) * 64;
-  const int i = blockIdx.y;
+  // row index i fastest: 64 consecutive workgroups read the 64 adjacent 512-byte rows of one P[item][f]
+  // matrix (one contiguous 32 KB region per f) instead of touching it 64 times far apart in time
+  const int i = blockIdx.x % m;
+  const long long tile_id = blockIdx.x / m;
+  const long long item = tile_id / nft;
+  const int f0 = (int)(tile_id % nft) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const double* P = a.P + ((size_t)item * F * MP + (size_t)i) * MP;   // + f*MP*MP + j
   // read: rows f, columns j (contiguous)
@@ -85,7 +88,7 @@ int launch_ffdtf_norm(const NormArgs& a, hipStream_t st) {
   if (a.n_items == 0) return 0;
   if (a.normalise)
     hipLaunchKernelGGL(den_kernel, dim3((unsigned)a.n_items), dim3(64), 0, st, a.rowsum, a.den, a.F, a.m_pad);
-  const dim3 grid((unsigned)(((a.F + 63) / 64) * a.n_items), a.m);
+  const dim3 grid((unsigned)(((a.F + 63) / 64) * a.n_items * a.m));
   hipLaunchKernelGGL(norm_kernel, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }

@@ -240,3 +240,23 @@ def test_two_stream_overlap_is_bit_identical():
     c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_multi_dyad_batch_matches_single_dyad_runs():
+    """Config 3 in miniature: several dyads in one batch (dyad x window items, forced into several chunks)
+    give bit-identical results to running each dyad alone -- the property dyad-sharding across GPUs relies on."""
+    eng = default_engine()
+    fs, w, p, T = 500.0, 1000, 8, 10_000
+    freqs = northstar_freqs(32)
+    xs = np.stack([synthetic_var_dyad(d, T=T) for d in (0, 1, 2)])
+    xd = eng.to_device(xs)
+    nw = 2 * T // w - 1
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    pos, w = window_positions(T, nw, w)
+    rec, st = window_items(3, pos, eng.device)
+    batch = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, chunk=7).view(3, nw, 64, 64, 32)
+    for d in range(3):
+        alone = sliding_ffdtf_device(xd[d:d + 1].contiguous(), w, nw, p, freqs, fs, eng)[0]
+        assert torch.equal(alone, batch[d])
+    ref = O.full_freq_dtf(xs[2][:, 500 * 5:500 * 5 + w], freqs, fs, p)
+    assert_parity(batch[2, 5].cpu().numpy(), ref)
