@@ -23,6 +23,11 @@ namespace hmv {
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
+// c - a*b: for the f64 MFMAs the BLGP field is NEG[2:0] (bit 0 negates A; checked on gfx950 with
+// tools/ubench_mfma_neg.hip), so a complex product needs no VALU negation of an operand.
+__device__ __forceinline__ double mfma4_nega(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1);
+}
 
 // compile-time loop: body(std::integral_constant<int, S>) for S = 0..N-1, always fully expanded so that
 // register-array indices stay static (a plain `#pragma unroll` is refused for bodies this large and

@@ -42,16 +42,14 @@ __global__ void __launch_bounds__(256) spectra_kernel(SpecArgs a) {
     for (int k0 = 0; k0 < MP; k0 += 4) {
       double av[NIW], bv[NJ];
 #pragma unroll
-      for (int ii = 0; ii < NIW; ++ii) {
-        const double v = xa[4 * ii * S + k0];
-        av[ii] = negate ? -v : v;
-      }
+      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * S + k0];
 #pragma unroll
       for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * S + k0];
 #pragma unroll
       for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
-        for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[ii], bv[J], acc[ii][J]);
+        for (int J = 0; J < NJ; ++J)
+          acc[ii][J] = negate ? mfma4_nega(av[ii], bv[J], acc[ii][J]) : mfma4(av[ii], bv[J], acc[ii][J]);
     }
   };
 

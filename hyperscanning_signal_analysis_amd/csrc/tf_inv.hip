@@ -346,15 +346,15 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         nvb = Ncur[(4 * (I + 3) + (l & 3)) * 4 + (l >> 4)];
       }
       const double dlt = ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
-      const double ar_ = (I == s) ? na.x - dlt : na.x, ai_ = na.y, an_ = -na.y;
-      const double br_ = (I + 1 == s) ? nb.x - dlt : nb.x, bi_ = nb.y, bn_ = -nb.y;
+      const double ar_ = (I == s) ? na.x - dlt : na.x, ai_ = na.y;
+      const double br_ = (I + 1 == s) ? nb.x - dlt : nb.x, bi_ = nb.y;
       re[I] = mfma4(ar_, ur, re[I]);
       im[I] = mfma4(ar_, ui, im[I]);
       re[I + 1] = mfma4(br_, ur, re[I + 1]);
       im[I + 1] = mfma4(br_, ui, im[I + 1]);
-      re[I] = mfma4(an_, ui, re[I]);
+      re[I] = mfma4_nega(ai_, ui, re[I]);          // re -= ai * ui  (NEG modifier, no VALU negation)
       im[I] = mfma4(ai_, ur, im[I]);
-      re[I + 1] = mfma4(bn_, ui, re[I + 1]);
+      re[I + 1] = mfma4_nega(bi_, ui, re[I + 1]);
       im[I + 1] = mfma4(bi_, ur, im[I + 1]);
     });
     HMV_T(4);
