@@ -20,7 +20,8 @@ import torch
 from .engine import Engine, SingularMatrixError, default_engine
 
 __all__ = ["count_corr", "ar_coeff", "mvar_transfer_function", "multivariate_spectra", "dtf_multivariate",
-           "full_freq_dtf", "mvar_criterion", "mvar_analysis", "lag_covariances"]
+           "full_freq_dtf", "mvar_criterion", "mvar_analysis", "lag_covariances", "compute_and_plot_mvar",
+           "mvar_plot"]
 
 
 # ----------------------------------------------------------------------------- internals
@@ -200,3 +201,77 @@ def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):
         plt.grid(True)
         plt.show()
     return crit, model_order_range, optimal_model_range
+
+
+def mvar_plot(spectra, ff_dtf, freqs, chan_names=None, top_title=""):
+    """Minimal m x m grid (|S_ii| on the diagonal, ffDTF j -> i elsewhere); own code, matplotlib only."""
+    import matplotlib.pyplot as plt
+    m = ff_dtf.shape[0]
+    names = list(chan_names) if chan_names is not None else [str(k) for k in range(m)]
+    fig, axs = plt.subplots(m, m, figsize=(10, 10), squeeze=False)
+    top = float(ff_dtf[~np.eye(m, dtype=bool)].max()) if m > 1 else 1.0
+    for i in range(m):
+        for j in range(m):
+            ax = axs[i, j]
+            if i == j:
+                ax.plot(freqs, np.abs(spectra[i, i, :]), color="k")
+            else:
+                ax.fill_between(freqs, ff_dtf[i, j, :], color="C0")
+                ax.set_ylim(0, top)
+            ax.tick_params(labelsize=5)
+            if i == 0:
+                ax.set_title(names[j], fontsize=7)
+            if j == 0:
+                ax.set_ylabel(names[i], fontsize=7)
+    fig.suptitle(top_title, fontsize=9)
+    return fig
+
+
+def compute_and_plot_mvar(ncdf_path, channel_subset=None, max_model_order=20, optimal_model_order=None,
+                          crit_type="AIC", freq_min=1.0, freq_max=40.0, freq_step=0.5, low_cutoff_hz=None,
+                          high_cutoff_hz=None, plot=True, plot_loaded_signal=False, loaded_signal_max_channels=19,
+                          loaded_signal_spacing=8.0, loaded_signal_figsize=(16.0, 9.0), loader=None):
+    """Load one EEG NetCDF file, compute ffDTF and multivariate spectra, optionally plot (mtmvar.py:1006-1128).
+
+    Returns (ff_dtf, spectra, chan_names, crit, model_order_range, p_opt) like the reference.  The
+    reference imports its loader from a module that does not define it; here it is wired
+    to `eeg_io.load_eeg_signals` (same semantics as `src/mne_bridge.py:113-223`), or to `loader=` if given.
+    One fit feeds both products.
+    """
+    if loader is None:
+        from .eeg_io import load_eeg_signals as loader
+    signals, chan_names, fs, time_s, event_duration_s = loader(
+        ncdf_path, channel_subset=channel_subset, low_cutoff_hz=low_cutoff_hz, high_cutoff_hz=high_cutoff_hz)
+    stem = ncdf_path.stem if hasattr(ncdf_path, "stem") else ncdf_path
+    if plot_loaded_signal:
+        import matplotlib.pyplot as plt
+        k = min(loaded_signal_max_channels, signals.shape[0])
+        plt.figure(figsize=loaded_signal_figsize)
+        for c in range(k):
+            plt.plot(time_s, signals[c] - c * loaded_signal_spacing, lw=0.6)
+        plt.yticks([-c * loaded_signal_spacing for c in range(k)], chan_names[:k])
+        plt.axvline(event_duration_s, color="r", lw=0.8)
+        plt.title(f"Loaded EEG signal — {stem}")
+        plt.show()
+    freqs = np.arange(freq_min, freq_max + freq_step, freq_step)
+    print(f"\n  Channels : {chan_names}")
+    print(f"  Signals  : {signals.shape}  fs={fs} Hz")
+    if optimal_model_order is None:
+        crit, model_order_range, p_opt = mvar_criterion(signals, max_model_order, crit_type, plot=False)
+        print(f"  {crit_type} optimal model order: p = {p_opt}")
+    else:
+        p_opt = optimal_model_order
+        print(f"  Using fixed model order: p = {p_opt}")
+        crit = np.array([])
+        model_order_range = np.array([])
+    print("  Computing ffDTF ...")
+    print("  Computing multivariate spectra ...")
+    res = mvar_analysis(signals, freqs, fs, int(p_opt), want=("ffdtf", "spectra"))
+    ff_dtf, spectra = res["ffdtf"], res["spectra"]
+    if plot:
+        import matplotlib.pyplot as plt
+        mvar_plot(spectra, ff_dtf, freqs, chan_names, top_title=f"MVAR Spectra and ff_DTF — {stem}")
+        plt.suptitle(f"{stem}  (fs={fs:.0f} Hz, {signals.shape[0]} ch, {signals.shape[1]} samp)", fontsize=8, y=1.01)
+        plt.tight_layout()
+        plt.show()
+    return ff_dtf, spectra, chan_names, crit, model_order_range, p_opt

@@ -71,3 +71,29 @@ def test_order_selection_path(tmp_path):
     _, _, want = O.mvar_criterion(x, 20, "AIC")
     assert int(p_opt) == int(want)
     assert np.allclose(ff, O.full_freq_dtf(x, pipe._freqs(), 8.0, int(want)), rtol=1e-7, atol=1e-12)
+
+
+def test_compute_and_plot_mvar_with_injected_loader(capsys):
+    """a11: single-file driver (mtmvar.py:1006-1128) with a working loader (reference import is broken, Q6)."""
+    from hyperscanning_signal_analysis_amd import mtmvar as M
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((5, 3000))
+    x[:, 1:] += 0.7 * x[:, :-1]
+    x = (x - x.mean(axis=1, keepdims=True)) / x.std(axis=1, keepdims=True)
+    names = ["Fz", "Cz", "Pz", "C3", "C4"]
+
+    def loader(path, channel_subset=None, low_cutoff_hz=None, high_cutoff_hz=None):
+        return x, names, 128.0, np.arange(3000) / 128.0, 3000 / 128.0
+
+    ff, sp, ch, crit, rng_, p_opt = M.compute_and_plot_mvar("W_001_EEG_ch_Peppa.nc", optimal_model_order=None,
+                                                            max_model_order=8, plot=False, loader=loader)
+    out = capsys.readouterr().out
+    assert "AIC optimal model order" in out and ch == names
+    freqs = np.arange(1.0, 40.0 + 0.5, 0.5)
+    _, _, want = O.mvar_criterion(x, 8, "AIC")
+    assert int(p_opt) == int(want) and len(crit) == 8 and list(rng_) == list(range(1, 9))
+    assert np.allclose(ff, O.full_freq_dtf(x, freqs, 128.0, int(want)), rtol=1e-7, atol=1e-12)
+    ref = O.multivariate_spectra(x, freqs, 128.0, int(want))
+    assert np.abs(sp - ref).max() <= 1e-8 * np.abs(ref).max()
+    ff2, _, _, crit2, rng2, p2 = M.compute_and_plot_mvar("x.nc", optimal_model_order=3, plot=False, loader=loader)
+    assert p2 == 3 and crit2.size == 0 and rng2.size == 0 and ff2.shape == (5, 5, 79)
