@@ -237,6 +237,23 @@ struct YwTile {
       Ys[trY ? col * S + row : row * S + col] = vy[r];
     }
   }
+  // split form for software pipelining: issue the global loads of the NEXT product's tiles, run the current
+  // product on the matrix pipe, then park the prefetched tiles in LDS
+  __device__ __forceinline__ void fetch2(double (&vx)[NPT], double (&vy)[NPT], const double* srcX, const double* srcY) const {
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) vx[r] = srcX[threadIdx.x + 256 * r];
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) vy[r] = srcY[threadIdx.x + 256 * r];
+  }
+  __device__ __forceinline__ void park2(const double (&vx)[NPT], const double (&vy)[NPT]) const {
+#pragma unroll
+    for (int r = 0; r < NPT; ++r) {
+      const int idx = threadIdx.x + 256 * r;
+      const int row = idx / MP, col = idx - row * MP;
+      Xs[row * S + col] = vx[r];
+      Ys[row * S + col] = vy[r];
+    }
+  }
   // acc[ii][J] += Xs(rows of this wave) * Ys^T
   __device__ __forceinline__ void gemm_nt(double (&acc)[NIW][NJ]) const {
     const double* xa = Xs + (4 * wv * NT + (l & 3)) * S + (l >> 4);
@@ -385,11 +402,16 @@ __global__ void __launch_bounds__(256, 2) yw_col_kernel(YwArgs a, int tb) {
   for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
     for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-  for (int c = 0; c < tb; ++c) {
-    __syncthreads();
-    t.stage2(q.Lt + yw_tri(ta, c) * TILE, false, q.Yt + yw_tri(tb, c) * TILE, false);
-    __syncthreads();
-    t.gemm_nt(acc);
+  {
+    double vx[T::NPT], vy[T::NPT];
+    if (tb > 0) t.fetch2(vx, vy, q.Lt + yw_tri(ta, 0) * TILE, q.Yt + yw_tri(tb, 0) * TILE);
+    for (int c = 0; c < tb; ++c) {
+      __syncthreads();                 // previous product has finished reading Xs / Ys
+      t.park2(vx, vy);
+      __syncthreads();
+      if (c + 1 < tb) t.fetch2(vx, vy, q.Lt + yw_tri(ta, c + 1) * TILE, q.Yt + yw_tri(tb, c + 1) * TILE);
+      t.gemm_nt(acc);                  // the next tiles' loads are in flight behind these MFMAs
+    }
   }
 #pragma unroll
   for (int ii = 0; ii < NIW; ++ii)
