@@ -12,10 +12,11 @@
 //
 // Design:
 //   * One workgroup of NT waves (MP = 16*NT <= 64 channels) owns one (window, frequency) matrix.  Wave w
-//     holds the 16 columns 16w..16w+15 of the MP x MP complex matrix in registers, in the D layout of
-//     hmv_common.h (lane (i = l>>4, cc = l&15) holds rows 4I+i of column 16w+cc in register [I]): 64
-//     VGPRs at MP = 64, so four workgroups are resident per CU and every SIMD has four waves to issue
-//     from while others wait on LDS, global memory or a barrier.
+//     holds the 16 columns 16w..16w+15 of the MP x MP complex matrix in registers with the four blocks of
+//     the 4x4x4 MFMA on four ROW blocks (lane (i, b, j) holds rows 16*Ig+4*b+i, columns 16w+4*Jl+j in
+//     register [Ig][Jl]), so ONE column block (= one pivot panel) can be updated by 4*NT MFMAs on its own:
+//     64 VGPRs at MP = 64, four workgroups resident per CU, four waves per SIMD to issue from while
+//     others wait on LDS, global memory or a barrier.
 //   * Inversion = in-place blocked Gauss-Jordan, 4 pivot columns per block step s:
 //       1. the wave that owns the panel columns (w = s / 4) moves them through LDS into a lane-per-row
 //          layout (64 rows = 64 lanes) and runs the four pivot steps: wave-wide arg-max of |re|+|im|
@@ -25,8 +26,8 @@
 //       2. workgroup barrier,
 //       3. every wave applies the interchanges to its own columns (rare; through LDS), then runs the rank-4
 //          update  M <- M + (N - E_S) * M[S, :]  of its column group on the matrix pipe: A operand
-//          (N - E_S) from LDS, B operand M[S, :] = the lane's own registers [s] (rows 4s..4s+3 of the D
-//          layout ARE the B-operand layout),
+//          (N - E_S) from LDS (NT reads per wave), B operand M[S, :] by one ds_bpermute inside the 16-lane
+//          row; the owner skips its own panel block (it is overwritten with N),
 //       4. the owner overwrites the panel columns with N and goes straight on to the next panel (its own
 //          column group is up to date) while the other waves finish: a natural one-step look-ahead.
 //     Row interchanges leave the inverse with permuted columns; `orig[c]` (LDS) tracks which original row
@@ -77,7 +78,7 @@ struct TfLds {
 
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfArgs a) {
-  constexpr int MP = 16 * NT, NI = 4 * NT, NSTEP = MP / 4;
+  constexpr int MP = 16 * NT, NG = NT, NSTEP = MP / 4;
   using L = TfLds<NT>;
   __shared__ double2 smem[L::TOTAL];
   __shared__ int s_orig[MP];
@@ -86,16 +87,19 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 
   const int l = lane_id();
   const int wv = uni(threadIdx.x >> 6);         // hardware wave index inside the workgroup
-  // Column group owned by this wave, rotated per workgroup: co-resident workgroups run in near lockstep
-  // and the hardware places wave k of every workgroup on the same SIMD, so without the rotation all four
-  // resident panel factorisations (one wave each) queue on ONE SIMD while the other three idle.
-  const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;   // hashed: block ids on one CU share low bits
+  // Column group owned by this wave, rotated per workgroup by a hash of the block id: co-resident
+  // workgroups run in near lockstep and wave k of every workgroup tends to sit on the same SIMD, so without
+  // the rotation the resident panel factorisations (one wave each) pile up on one SIMD.
+  const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;
   const long long gw = blockIdx.x;              // item * F + f
   const int item = uni((int)(blockIdx.x / (unsigned)a.F));   // wave-uniform: keep it in SGPRs
   const int f = uni((int)(blockIdx.x - (unsigned)item * (unsigned)a.F));
   const int p = a.p;
-  const int i = l >> 4, cc = l & 15;
-  const int mycol = 16 * w + cc;
+  // "X layout" (hmv_common.h lane maps with the four MFMA blocks on four ROW blocks): lane (i, b, j) holds
+  // rows 16*Ig + 4*b + i and columns col0 + 4*Jl + j in register [Ig][Jl].
+  const int i = l >> 4, b = (l >> 2) & 3, j = l & 3;
+  const int rowl = 4 * b + i;                   // row inside a 16-row group
+  const int col0 = 16 * w;
 
   double2* Pbuf = smem;
   double2* Nbuf = Pbuf + L::PBUF;
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   double2* swapb = Srow + L::SROW + wv * 32;
   double* rsum = reinterpret_cast<double*>(Srow + L::SROW + L::SWAPB);
 
-  double re[NI], im[NI];
+  double re[NG][4], im[NG][4];
 #ifdef HMV_STAMP
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
@@ -114,14 +118,16 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     const double* ar = a.ar + (size_t)item * MP * MP * p;
     const double* tw = a.tw + (size_t)f * p * 2;
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
-      re[I] = (4 * I + i == mycol) ? 1.0 : 0.0;
-      im[I] = 0.0;
-    }
-    const double* e0 = ar + ((size_t)i * MP + mycol) * p;
-    // Lag chunks of KC coefficients; a batch of 2-4 row blocks issues all of its 16-byte loads before the
-    // first FMA (explicit staging array + sched_barrier: left alone the compiler serialises every load
-    // behind an s_waitcnt).  KC = 8 reads each element's 64 contiguous bytes exactly once.
+    for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+      for (int Jl = 0; Jl < 4; ++Jl) {
+        re[Ig][Jl] = (16 * Ig + rowl == col0 + 4 * Jl + j) ? 1.0 : 0.0;
+        im[Ig][Jl] = 0.0;
+      }
+    const double* e0 = ar + ((size_t)rowl * MP + col0 + j) * p;
+    // Lag chunks of KC coefficients; a batch (two column blocks of one row group) issues all of its 16-byte
+    // loads before the first FMA (explicit staging array + sched_barrier: left alone the compiler
+    // serialises every load behind an s_waitcnt).  KC = 8 reads each element's 64 contiguous bytes once.
     auto chunk = [&](auto kc_tag, int k0) __attribute__((always_inline)) {
       constexpr int KC = decltype(kc_tag)::value;
       double zr[KC], zi[KC];
@@ -130,20 +136,19 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         zr[k] = tw[2 * (k0 + k)];
         zi[k] = tw[2 * (k0 + k) + 1];
       }
-      constexpr int NB = (KC >= 8) ? 2 : 4;                  // row blocks per batch (register budget: 128 VGPRs)
-      static_for<NI / NB>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int I0 = NB * decltype(ic)::value;
-        double2 v[NB][KC / 2];
+      static_for<NG * 2>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int Ig = decltype(bc)::value >> 1, J0 = 2 * (decltype(bc)::value & 1);
+        double2 v[2][KC / 2];
 #pragma unroll
-        for (int d = 0; d < NB; ++d) {
-          const double2* e = reinterpret_cast<const double2*>(e0 + (size_t)(4 * (I0 + d)) * MP * p + k0);
+        for (int d = 0; d < 2; ++d) {
+          const double2* e = reinterpret_cast<const double2*>(e0 + ((size_t)(16 * Ig) * MP + 4 * (J0 + d)) * p + k0);
 #pragma unroll
           for (int h = 0; h < KC / 2; ++h) v[d][h] = e[h];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int d = 0; d < NB; ++d) {
-          double sr = re[I0 + d], si = im[I0 + d];
+        for (int d = 0; d < 2; ++d) {
+          double sr = re[Ig][J0 + d], si = im[Ig][J0 + d];
 #pragma unroll
           for (int h = 0; h < KC / 2; ++h) {
             sr = __builtin_fma(-v[d][h].x, zr[2 * h], sr);
@@ -151,8 +156,8 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
             sr = __builtin_fma(-v[d][h].y, zr[2 * h + 1], sr);
             si = __builtin_fma(-v[d][h].y, zi[2 * h + 1], si);
           }
-          re[I0 + d] = sr;
-          im[I0 + d] = si;
+          re[Ig][J0 + d] = sr;
+          im[Ig][J0 + d] = si;
         }
       });
     };
@@ -163,19 +168,25 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     }
     for (; k0 < p; ++k0) {
       const double zr = tw[2 * k0], zi = tw[2 * k0 + 1];
-      double v[NI];
+      double v[NG][4];
 #pragma unroll
-      for (int I = 0; I < NI; ++I) v[I] = e0[(size_t)(4 * I) * MP * p + k0];
+      for (int Ig = 0; Ig < NG; ++Ig)
 #pragma unroll
-      for (int I = 0; I < NI; ++I) {
-        re[I] = __builtin_fma(-v[I], zr, re[I]);
-        im[I] = __builtin_fma(-v[I], zi, im[I]);
-      }
+        for (int Jl = 0; Jl < 4; ++Jl) v[Ig][Jl] = e0[((size_t)(16 * Ig) * MP + 4 * Jl) * p + k0];
+#pragma unroll
+      for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+        for (int Jl = 0; Jl < 4; ++Jl) {
+          re[Ig][Jl] = __builtin_fma(-v[Ig][Jl], zr, re[Ig][Jl]);
+          im[Ig][Jl] = __builtin_fma(-v[Ig][Jl], zi, im[Ig][Jl]);
+        }
     }
     if (a.A) {
-      double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP;
+      double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP + (size_t)rowl * MP + col0 + j;
 #pragma unroll
-      for (int I = 0; I < NI; ++I) Ao[(size_t)(4 * I + i) * MP + mycol] = make_double2(re[I], im[I]);
+      for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+        for (int Jl = 0; Jl < 4; ++Jl) Ao[(size_t)(16 * Ig) * MP + 4 * Jl] = make_double2(re[Ig][Jl], im[Ig][Jl]);
     }
   }
   if (w == 0) {
@@ -188,19 +199,18 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   // ---------------------------------------------------------------- blocked Gauss-Jordan
   static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
-    constexpr int ws = s >> 2, q = s & 3;
+    constexpr int ws = s >> 2;        // owner wave (column group) AND 16-row group of the pivot rows 4s..4s+3
+    constexpr int q = s & 3;          // column block of the panel inside the owner, and b of the pivot rows
     double2* Ncur = Nbuf + (s & 1) * L::NBUF;
     HMV_T(5);
 
     if (w == ws) {
       // ---- 1. panel -> LDS -> lane-per-row, four pivot steps (this wave only).  The factorisation is the
-      // workgroup's critical path (three waves wait for it), so it outranks the other workgroups' MFMA work
-      // on this SIMD.
+      // workgroup's critical path (the other waves wait for it), so it outranks the other workgroups' MFMA
+      // work on this SIMD.
       __builtin_amdgcn_s_setprio(3);
-      if ((cc >> 2) == q) {
 #pragma unroll
-        for (int I = 0; I < NI; ++I) Pbuf[(4 * I + i) * 5 + (cc & 3)] = make_double2(re[I], im[I]);
-      }
+      for (int Ig = 0; Ig < NG; ++Ig) Pbuf[(16 * Ig + rowl) * 5 + j] = make_double2(re[Ig][q], im[Ig][q]);
       HMV_LDS_FENCE();
       double2 x[4];     // (re, im) adjacent: LDS transfers need no register shuffling
       {
@@ -298,9 +308,10 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 
     HMV_T(2);
     // ---- 3a. pending row interchanges on this wave's columns
-    // first A operands and the interchange list are fetched together: one LDS round trip after the barrier
-    double2 nva = Ncur[(l & 3) * 4 + (l >> 4)];
-    double2 nvb = Ncur[(4 + (l & 3)) * 4 + (l >> 4)];
+    // A operands (N - E_S, rows 16*Ig + (l & 15), k = l >> 4) and the interchange list: one LDS round trip
+    double2 nv[NG];
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig) nv[Ig] = Ncur[(16 * Ig + (l & 15)) * 4 + (l >> 4)];
     const int4 swv = *reinterpret_cast<const int4*>(&s_swp[s & 1][0]);
     const int swr[4] = {uni(swv.x), uni(swv.y), uni(swv.z), uni(swv.w)};
 #pragma unroll
@@ -308,91 +319,116 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       const int col = 4 * s + jj;
       const int rstar = swr[jj];
       if (rstar != col) {
-        const int Ist = rstar >> 2, ist = rstar & 3;
-        if (i == jj) swapb[cc] = make_double2(re[s], im[s]);
+        // row `col` = (Ig ws, b q, i jj); row rstar = (Ig rstar>>4, b (rstar>>2)&3, i rstar&3)
+        const int Igs = rstar >> 4, bs = (rstar >> 2) & 3, is = rstar & 3;
+        if (i == jj && b == q) {
+#pragma unroll
+          for (int Jl = 0; Jl < 4; ++Jl) swapb[Jl * 4 + j] = make_double2(re[ws][Jl], im[ws][Jl]);
+        }
         HMV_LDS_FENCE();
-        // expanded at compile time (a run-time loop here is folded into re[Ist], i.e. scratch)
-        static_for<NI - s>([&](auto ic) __attribute__((always_inline)) {
-          constexpr int I = s + decltype(ic)::value;
-          if (I == Ist) {
-            if (i == ist) {
-              swapb[16 + cc] = make_double2(re[I], im[I]);
-              const double2 v = swapb[cc];
-              re[I] = v.x;
-              im[I] = v.y;
+        // expanded at compile time (a run-time loop here is folded into re[Igs], i.e. scratch)
+        static_for<NG - ws>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int Ig = ws + decltype(ic)::value;
+          if (Ig == Igs) {
+            if (i == is && b == bs) {
+#pragma unroll
+              for (int Jl = 0; Jl < 4; ++Jl) swapb[16 + Jl * 4 + j] = make_double2(re[Ig][Jl], im[Ig][Jl]);
+#pragma unroll
+              for (int Jl = 0; Jl < 4; ++Jl) {
+                const double2 v = swapb[Jl * 4 + j];
+                re[Ig][Jl] = v.x;
+                im[Ig][Jl] = v.y;
+              }
             }
           }
         });
         HMV_LDS_FENCE();
-        if (i == jj) {
-          const double2 v = swapb[16 + cc];
-          re[s] = v.x;
-          im[s] = v.y;
+        if (i == jj && b == q) {
+#pragma unroll
+          for (int Jl = 0; Jl < 4; ++Jl) {
+            const double2 v = swapb[16 + Jl * 4 + j];
+            re[ws][Jl] = v.x;
+            im[ws][Jl] = v.y;
+          }
         }
         HMV_LDS_FENCE();
       }
     }
     HMV_T(3);
-    // ---- 3b. rank-4 update of this wave's column group on the matrix pipe
-    const double ur = re[s], ui = im[s];
-    // Two row blocks per iteration: the second MFMA on an accumulator is issued four MFMAs after the first
-    // (dependent-accumulator latency), and the A operands of the next pair are fetched from LDS before
-    // this pair's MFMAs are issued.
-    static_for<NI / 2>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int I = 2 * decltype(ic)::value;
-      const double2 na = nva, nb = nvb;
-      if (I + 2 < NI) {
-        nva = Ncur[(4 * (I + 2) + (l & 3)) * 4 + (l >> 4)];
-        nvb = Ncur[(4 * (I + 3) + (l & 3)) * 4 + (l >> 4)];
+    // ---- 3b. rank-4 update of this wave's 16 columns on the matrix pipe.  B operand: pivot row 4s+k at
+    // this lane's column, held by lane (i = k, b = q, j) in register [ws][Jl] -> one bpermute inside the
+    // 16-lane row; A operand: nv (minus the identity on the pivot rows).
+    const int bsrc = (l & 0x33) | (q << 2);
+    double ur[4], ui[4];
+#pragma unroll
+    for (int Jl = 0; Jl < 4; ++Jl) {
+      ur[Jl] = shfl_f64(re[ws][Jl], bsrc);
+      ui[Jl] = shfl_f64(im[ws][Jl], bsrc);
+    }
+    const double dlt = (b == q && j == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int Jl = 0; Jl < 4; ++Jl) {
+      // the owner's own panel block is overwritten with N below: its MFMAs would be wasted
+      if (w != ws || Jl != q) {
+#pragma unroll
+        for (int Ig = 0; Ig < NG; ++Ig) {
+          const double ar_ = (Ig == ws) ? nv[Ig].x - dlt : nv[Ig].x;
+          re[Ig][Jl] = mfma4(ar_, ur[Jl], re[Ig][Jl]);
+          im[Ig][Jl] = mfma4(ar_, ui[Jl], im[Ig][Jl]);
+        }
+#pragma unroll
+        for (int Ig = 0; Ig < NG; ++Ig) {
+          re[Ig][Jl] = mfma4_nega(nv[Ig].y, ui[Jl], re[Ig][Jl]);     // re -= ni * ui (NEG modifier)
+          im[Ig][Jl] = mfma4(nv[Ig].y, ur[Jl], im[Ig][Jl]);
+        }
       }
-      const double dlt = ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
-      const double ar_ = (I == s) ? na.x - dlt : na.x, ai_ = na.y;
-      const double br_ = (I + 1 == s) ? nb.x - dlt : nb.x, bi_ = nb.y;
-      re[I] = mfma4(ar_, ur, re[I]);
-      im[I] = mfma4(ar_, ui, im[I]);
-      re[I + 1] = mfma4(br_, ur, re[I + 1]);
-      im[I + 1] = mfma4(br_, ui, im[I + 1]);
-      re[I] = mfma4_nega(ai_, ui, re[I]);          // re -= ai * ui  (NEG modifier, no VALU negation)
-      im[I] = mfma4(ai_, ur, im[I]);
-      re[I + 1] = mfma4_nega(bi_, ui, re[I + 1]);
-      im[I + 1] = mfma4(bi_, ur, im[I + 1]);
-    });
+    }
     HMV_T(4);
     // ---- 4. panel columns <- N (owner wave)
-    if (w == ws && (cc >> 2) == q) {
+    if (w == ws) {
 #pragma unroll
-      for (int I = 0; I < NI; ++I) {
-        const double2 v = Ncur[(4 * I + i) * 4 + (cc & 3)];
-        re[I] = v.x;
-        im[I] = v.y;
+      for (int Ig = 0; Ig < NG; ++Ig) {
+        const double2 v = Ncur[(16 * Ig + rowl) * 4 + j];
+        re[Ig][q] = v.x;
+        im[Ig][q] = v.y;
       }
     }
   });
 
   HMV_T(5);
   // ---------------------------------------------------------------- outputs
-  // Lane coordinates are re-derived from an opaque lane id: reusing `i` would keep the 15 row indices
-  // 4I+i of the prologue alive across the whole sweep (they were spilled to scratch: 2.5 GB per launch).
+  // Lane coordinates are re-derived from an opaque lane id: reusing the prologue's row indices would keep
+  // them alive across the whole sweep (they were spilled to scratch once: 2.5 GB per launch).
   int lo;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-  const int io = lo >> 4, cco = lo & 15;
-  const int oc = s_orig[16 * w + cco];      // last written before the final barrier of the sweep
-  if (w == 0 && l == 0) a.info[gw] = s_info;
+  const int rowo = 4 * ((lo >> 2) & 3) + (lo >> 4), jo = lo & 3;
+  int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
+#pragma unroll
+  for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[16 * w + 4 * Jl + jo];
+  if (w == 0 && lo == 0) a.info[gw] = s_info;
 
   if (a.H) {
-    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)io * MP + oc;
+    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)rowo * MP;
 #pragma unroll
-    for (int I = 0; I < NI; ++I) Ho[(size_t)(4 * I) * MP] = make_double2(re[I], im[I]);
+    for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+      for (int Jl = 0; Jl < 4; ++Jl) Ho[(size_t)(16 * Ig) * MP + oc[Jl]] = make_double2(re[Ig][Jl], im[Ig][Jl]);
   }
   if (a.P) {
-    double* Po = a.P + (size_t)gw * MP * MP + (size_t)io * MP + oc;
-    double* rs = rsum + w * MP + io;
+    double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
+    double* rs = rsum + w * MP + rowo;
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
-      const double v = re[I] * re[I] + im[I] * im[I];
-      Po[(size_t)(4 * I) * MP] = v;
-      const double acc = row16_sum_dpp(v);
-      if (cco == 0) rs[4 * I] = acc;
+    for (int Ig = 0; Ig < NG; ++Ig) {
+      double acc = 0.0;
+#pragma unroll
+      for (int Jl = 0; Jl < 4; ++Jl) {
+        const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
+        Po[(size_t)(16 * Ig) * MP + oc[Jl]] = v;
+        acc += v;
+      }
+      acc += dpp_f64<0xB1>(acc);      // sum over the four lanes j of the quad (fixed order)
+      acc += dpp_f64<0x4E>(acc);
+      if (jo == 0) rs[16 * Ig] = acc;
     }
     __syncthreads();
     if (w == 0 && lo < MP) {
@@ -409,7 +445,6 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   }
 #endif
 }
-
 
 // ---------------------------------------------------------------- twiddles
 // tw[f][k] = exp(-(k+1) * 2*pi*1j * freqs[f] / fs), same operation order as mtmvar.py:153.
