@@ -102,13 +102,17 @@ __device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
       : "+v"(v));
   return v;
 }
-// wave-uniform max of a 32-bit key over the 64 lanes (returned in an SGPR)
+// wave-uniform max of a 32-bit key over the 64 lanes (returned in an SGPR): row maxima, then the two
+// wave-level DPP broadcasts (lane 15 of row r into row r+1 for rows 1 and 3; lane 31 into rows 2 and 3)
+// leave the maximum in lane 63 -- 6 DPP ops + 1 v_readlane instead of 4 v_readlane + scalar/vector maxes.
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = row16_max_u32(v);
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
+  asm("v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {

@@ -169,6 +169,24 @@ def test_transfer_inverse_needs_pivoting(m):
     assert np.abs(eye - np.eye(m)[:, :, None]).max() < 1e-9
 
 
+@pytest.mark.parametrize("m,shift", [(64, 1), (64, 16), (64, 17), (64, 32), (64, 47), (64, 63), (48, 31), (20, 7)])
+def test_transfer_inverse_scaled_permutation(m, shift):
+    """At f = 0 an order-1 model with A_1 = I - P D has A(0) = P D, a scaled cyclic permutation: every pivot
+    column holds exactly one non-zero, `shift` rows below the diagonal (crossing the 16-lane DPP rows of the
+    wave-wide arg-max), so any error in the pivot search shows up as a singular flag or a wrong inverse."""
+    rng = np.random.default_rng(1000 + shift)
+    d = rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m)
+    PD = np.zeros((m, m))
+    PD[(np.arange(m) + shift) % m, np.arange(m)] = d
+    ar = (np.eye(m) - PD)[:, :, None]
+    freqs = np.array([0.0, 64.0])                    # z = 1 and z = -1 at fs = 128
+    H, A = M.mvar_transfer_function(ar, freqs, 128.0)
+    assert_parity(A[:, :, 0], PD.astype(complex), 1e-15)
+    assert_parity(H[:, :, 0], np.linalg.inv(PD).astype(complex), 1e-14)
+    Ho, _ = O.mvar_transfer_function(ar, freqs, 128.0)
+    assert_parity(H, Ho, 1e-12)
+
+
 def test_pivot_threshold_variants_agree():
     from hyperscanning_signal_analysis_amd.engine import Engine
     rng = np.random.default_rng(9)
