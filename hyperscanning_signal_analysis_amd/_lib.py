@@ -23,8 +23,9 @@ SIGNATURES = {
     "hmv_yw_solve_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "hmv_twiddles_f64": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p]),
+    "hmv_tf_workspace_doubles": (c_int64, [c_int64, c_int, c_int]),
     "hmv_tf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                           c_void_p, c_void_p, c_double, c_void_p]),
+                           c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "hmv_ffdtf_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                    c_void_p]),
     "hmv_transpose_c128": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -68,16 +68,23 @@ int hmv_twiddles_f64(const double* freqs, int F, double fs, int p, double* tw, v
   return hmv::launch_twiddles(freqs, F, fs, p, tw, S(stream));
 }
 
+int64_t hmv_tf_workspace_doubles(int64_t n_items, int m, int p) {
+  const int mp = pad_of(m);
+  if (mp < 0 || p < 1 || n_items < 0) return -1;
+  return (int64_t)hmv::tf_workspace_doubles(n_items, mp, p);
+}
+
 int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* P,
-               double* rowsum, double* H, double* A, int32_t* info, double pivot_tau, void* stream) {
+               double* rowsum, double* H, double* A, int32_t* info, double pivot_tau, double* ws,
+               void* stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_tf_f64: channel count must be in 1..64");
   if (p < 1) return fail(-2, "hmv_tf_f64: model order must be >= 1");
-  if (!ar || !tw || !info || n_items < 0 || F < 0) return fail(-4, "hmv_tf_f64: null pointer");
+  if (!ar || !tw || !info || !ws || n_items < 0 || F < 0) return fail(-4, "hmv_tf_f64: null pointer");
   if ((P == nullptr) != (rowsum == nullptr)) return fail(-5, "hmv_tf_f64: P and rowsum go together");
   if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_f64: pivot_tau must be in (0, 1]");
   hmv::TfArgs a;
-  a.ar = ar; a.tw = tw; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
+  a.ar = ar; a.arx = ws; a.tw = tw; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
   a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   a.stamps = nullptr;
 #ifdef HMV_STAMP
@@ -116,7 +123,7 @@ int hmv_spectra_f64(const double* H, const double* V, double* Sout, int64_t n_it
 // ---- fused sliding-window path ----------------------------------------------------------------------
 namespace {
 struct SlidingWs {
-  size_t off_R, off_ws, off_ar, off_V, off_P, off_rowsum, off_den, off_tw, total;
+  size_t off_R, off_ws, off_ar, off_arx, off_V, off_P, off_rowsum, off_den, off_tw, total;
 };
 SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   SlidingWs w;
@@ -125,6 +132,7 @@ SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   w.off_R = o;      o += align256(sizeof(double) * chunk * (p + 1) * t);
   w.off_ws = o;     o += align256(sizeof(double) * chunk * hmv::yw_ws_tiles(p) * t);
   w.off_ar = o;     o += align256(sizeof(double) * chunk * t * p);
+  w.off_arx = o;    o += align256(sizeof(double) * hmv::tf_workspace_doubles(chunk, mp, p));
   w.off_V = o;      o += align256(sizeof(double) * chunk * t);
   w.off_P = o;      o += align256(sizeof(double) * chunk * F * t);
   w.off_rowsum = o; o += align256(sizeof(double) * chunk * F * mp);
@@ -176,6 +184,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     double* R = reinterpret_cast<double*>(base + w.off_R);
     double* ws = reinterpret_cast<double*>(base + w.off_ws);
     double* ar = reinterpret_cast<double*>(base + w.off_ar);
+    double* arx = reinterpret_cast<double*>(base + w.off_arx);
     double* V = reinterpret_cast<double*>(base + w.off_V);
     double* P = reinterpret_cast<double*>(base + w.off_P);
     double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
@@ -195,7 +204,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
     if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), S(s));
-    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, s);
+    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, arx, s);
     if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), S(s));
     if (rc) break;
     rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, s);

@@ -34,7 +34,8 @@ int launch_yw(const YwArgs& a, int m_pad, hipStream_t st);
 
 // ---- K3 transfer matrix inverse ---------------------------------------------------------------
 struct TfArgs {
-  const double* ar;         // [n_items][MP][MP][p]
+  const double* ar;         // [n_items][MP][MP][p]  (reference layout; read by the packing kernel only)
+  const double* arx;        // scratch, tf_workspace_doubles(): the same coefficients in K3's register order
   const double* tw;         // [F][p][2]
   double* P;                // optional [n_items][F][MP][MP]
   double* rowsum;           // required with P: [n_items][F][MP]
@@ -48,6 +49,7 @@ struct TfArgs {
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
 int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);
+long long tf_workspace_doubles(long long n_items, int m_pad, int p);
 
 // ---- K4 ffDTF normalisation + layout transposes -------------------------------------------------
 struct NormArgs {

@@ -115,7 +115,12 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 
   // ---------------------------------------------------------------- A(f), this wave's 16 columns
   {
-    const double* ar = a.ar + (size_t)item * MP * MP * p;
+    // Coefficients in the packed layout written by ar_pack_kernel: for wave w, register (Ig, Jl) and lag pair
+    // h the 64 lanes' (a[2h], a[2h+1]) are 1 KB contiguous, so every load instruction is one fully coalesced
+    // 16-B/lane read (the reference (m, m, p) layout costs 64 partial cache lines per instruction).
+    const int P2 = (p + 1) >> 1;
+    const double2* ax = reinterpret_cast<const double2*>(a.arx) +
+                        ((size_t)item * NT + w) * (size_t)(NG * 4 * 64) * P2 + l;
     const double* tw = a.tw + (size_t)f * p * 2;
 #pragma unroll
     for (int Ig = 0; Ig < NG; ++Ig)
@@ -124,33 +129,33 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         re[Ig][Jl] = (16 * Ig + rowl == col0 + 4 * Jl + j) ? 1.0 : 0.0;
         im[Ig][Jl] = 0.0;
       }
-    const double* e0 = ar + ((size_t)rowl * MP + col0 + j) * p;
-    // Lag chunks of KC coefficients; a batch (two column blocks of one row group) issues all of its 16-byte
-    // loads before the first FMA (explicit staging array + sched_barrier: left alone the compiler
-    // serialises every load behind an s_waitcnt).  KC = 8 reads each element's 64 contiguous bytes once.
-    auto chunk = [&](auto kc_tag, int k0) __attribute__((always_inline)) {
-      constexpr int KC = decltype(kc_tag)::value;
-      double zr[KC], zi[KC];
+    // Chunks of HC lag pairs; a batch (two column blocks of one row group) issues all of its loads before
+    // the first FMA (explicit staging array + sched_barrier: left alone the compiler serialises every load
+    // behind an s_waitcnt).
+    auto chunk = [&](auto hc_tag, int h0) __attribute__((always_inline)) {
+      constexpr int HC = decltype(hc_tag)::value;
+      double zr[2 * HC], zi[2 * HC];
 #pragma unroll
-      for (int k = 0; k < KC; ++k) {
-        zr[k] = tw[2 * (k0 + k)];
-        zi[k] = tw[2 * (k0 + k) + 1];
+      for (int k = 0; k < 2 * HC; ++k) {
+        const int lag = 2 * h0 + k;          // the padding lag of an odd order has a zero coefficient
+        zr[k] = (lag < p) ? tw[2 * lag] : 0.0;
+        zi[k] = (lag < p) ? tw[2 * lag + 1] : 0.0;
       }
       static_for<NG * 2>([&](auto bc) __attribute__((always_inline)) {
         constexpr int Ig = decltype(bc)::value >> 1, J0 = 2 * (decltype(bc)::value & 1);
-        double2 v[2][KC / 2];
+        double2 v[2][HC];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const double2* e = reinterpret_cast<const double2*>(e0 + ((size_t)(16 * Ig) * MP + 4 * (J0 + d)) * p + k0);
+          const double2* e = ax + ((size_t)((Ig * 4 + J0 + d) * P2 + h0)) * 64;
 #pragma unroll
-          for (int h = 0; h < KC / 2; ++h) v[d][h] = e[h];
+          for (int h = 0; h < HC; ++h) v[d][h] = e[h * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           double sr = re[Ig][J0 + d], si = im[Ig][J0 + d];
 #pragma unroll
-          for (int h = 0; h < KC / 2; ++h) {
+          for (int h = 0; h < HC; ++h) {
             sr = __builtin_fma(-v[d][h].x, zr[2 * h], sr);
             si = __builtin_fma(-v[d][h].x, zi[2 * h], si);
             sr = __builtin_fma(-v[d][h].y, zr[2 * h + 1], sr);
@@ -161,26 +166,9 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         }
       });
     };
-    int k0 = 0;
-    if ((p & 1) == 0) {
-      for (; k0 + 8 <= p; k0 += 8) chunk(std::integral_constant<int, 8>{}, k0);
-      for (; k0 + 2 <= p; k0 += 2) chunk(std::integral_constant<int, 2>{}, k0);
-    }
-    for (; k0 < p; ++k0) {
-      const double zr = tw[2 * k0], zi = tw[2 * k0 + 1];
-      double v[NG][4];
-#pragma unroll
-      for (int Ig = 0; Ig < NG; ++Ig)
-#pragma unroll
-        for (int Jl = 0; Jl < 4; ++Jl) v[Ig][Jl] = e0[((size_t)(16 * Ig) * MP + 4 * Jl) * p + k0];
-#pragma unroll
-      for (int Ig = 0; Ig < NG; ++Ig)
-#pragma unroll
-        for (int Jl = 0; Jl < 4; ++Jl) {
-          re[Ig][Jl] = __builtin_fma(-v[Ig][Jl], zr, re[Ig][Jl]);
-          im[Ig][Jl] = __builtin_fma(-v[Ig][Jl], zi, im[Ig][Jl]);
-        }
-    }
+    int h0 = 0;
+    for (; h0 + 4 <= P2; h0 += 4) chunk(std::integral_constant<int, 4>{}, h0);
+    for (; h0 < P2; ++h0) chunk(std::integral_constant<int, 1>{}, h0);
     if (a.A) {
       double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP + (size_t)rowl * MP + col0 + j;
 #pragma unroll
@@ -444,6 +432,33 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 #endif
 }
 
+// ---------------------------------------------------------------- coefficient packing
+// ar (reference layout [item][row][col][lag], rows/cols padded to MP) -> arx[item][w][Ig][Jl][h][lane][2]:
+// lane (i, b, j) of wave w finds lags (2h, 2h+1) of element (16*Ig + 4*b + i, 16*w + 4*Jl + j) at its own
+// 16-byte slot (zero for the padding lag of an odd order).  262 KB per item, once per item instead of once
+// per (item, frequency).
+template <int NT>
+__global__ void __launch_bounds__(256) ar_pack_kernel(const double* ar, double* arx, long long n_items, int p) {
+  constexpr int MP = 16 * NT;
+  const int P2 = (p + 1) >> 1;
+  const long long per_item = (long long)MP * MP * P2;       // double2 slots
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_items * per_item) return;
+  const long long item = idx / per_item;
+  long long r = idx - item * per_item;
+  const int lane = (int)(r & 63); r >>= 6;
+  const int h = (int)(r % P2); r /= P2;
+  const int Jl = (int)(r & 3); r >>= 2;
+  const int Ig = (int)(r % NT);
+  const int w = (int)(r / NT);
+  const int row = 16 * Ig + 4 * ((lane >> 2) & 3) + (lane >> 4), col = 16 * w + 4 * Jl + (lane & 3);
+  const double* e = ar + ((size_t)item * MP * MP + (size_t)row * MP + col) * p;
+  double2 v;
+  v.x = e[2 * h];
+  v.y = (2 * h + 1 < p) ? e[2 * h + 1] : 0.0;
+  reinterpret_cast<double2*>(arx)[idx] = v;
+}
+
 // ---------------------------------------------------------------- twiddles
 // tw[f][k] = exp(-(k+1) * 2*pi*1j * freqs[f] / fs), same operation order as mtmvar.py:153.
 __global__ void twiddle_kernel(const double* freqs, int F, double fs, int p, double* tw) {
@@ -464,15 +479,34 @@ int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hi
   return (int)hipGetLastError();
 }
 
+long long tf_workspace_doubles(long long n_items, int m_pad, int p) {
+  return n_items * (long long)m_pad * m_pad * 2 * ((p + 1) / 2);
+}
+
 int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st) {
   const long long n = a.n_items * (long long)a.F;
   if (n == 0) return 0;
   const dim3 grid((unsigned)n);
+  const long long slots = a.n_items * (long long)m_pad * m_pad * ((a.p + 1) / 2);
+  const dim3 pgrid((unsigned)((slots + 255) / 256));
+  double* arx = const_cast<double*>(a.arx);
   switch (m_pad) {
-    case 16: hipLaunchKernelGGL(tf_inv_kernel<1>, grid, dim3(64), 0, st, a); break;
-    case 32: hipLaunchKernelGGL(tf_inv_kernel<2>, grid, dim3(128), 0, st, a); break;
-    case 48: hipLaunchKernelGGL(tf_inv_kernel<3>, grid, dim3(192), 0, st, a); break;
-    case 64: hipLaunchKernelGGL(tf_inv_kernel<4>, grid, dim3(256), 0, st, a); break;
+    case 16:
+      hipLaunchKernelGGL(ar_pack_kernel<1>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
+      hipLaunchKernelGGL(tf_inv_kernel<1>, grid, dim3(64), 0, st, a);
+      break;
+    case 32:
+      hipLaunchKernelGGL(ar_pack_kernel<2>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
+      hipLaunchKernelGGL(tf_inv_kernel<2>, grid, dim3(128), 0, st, a);
+      break;
+    case 48:
+      hipLaunchKernelGGL(ar_pack_kernel<3>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
+      hipLaunchKernelGGL(tf_inv_kernel<3>, grid, dim3(192), 0, st, a);
+      break;
+    case 64:
+      hipLaunchKernelGGL(ar_pack_kernel<4>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
+      hipLaunchKernelGGL(tf_inv_kernel<4>, grid, dim3(256), 0, st, a);
+      break;
     default: return -1;
   }
   return (int)hipGetLastError();

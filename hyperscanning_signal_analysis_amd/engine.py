@@ -119,9 +119,11 @@ class Engine:
         H = self.empty(n_items, F, mp, mp, 2) if want_H else None
         A = self.empty(n_items, F, mp, mp, 2) if want_A else None
         info = self.empty(n_items * F, dtype=torch.int32)
+        ws = self.empty(max(1, int(self.lib.hmv_tf_workspace_doubles(n_items, m, p))))
         with torch.cuda.device(self.device):
             rc = self.lib.hmv_tf_f64(ar.data_ptr(), n_items, m, p, tw.data_ptr(), F, _ptr(P), _ptr(rowsum),
-                                     _ptr(H), _ptr(A), info.data_ptr(), self.pivot_tau, self.stream())
+                                     _ptr(H), _ptr(A), info.data_ptr(), self.pivot_tau, ws.data_ptr(),
+                                     self.stream())
         _lib.check(rc, "hmv_tf_f64")
         out.update(P=P, rowsum=rowsum, H=H, A=A, info=info)
         return out

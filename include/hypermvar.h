@@ -64,10 +64,13 @@ int hmv_twiddles_f64(const double* freqs, int F, double fs, int p, double* tw, v
  * Optional outputs (NULL to skip), kernel-natural layout [item][f][MP][MP]:
  *   P = |H|^2 with rowsum[item][f][MP] = sum_j |H_ij|^2 (required together), H, A (complex128 interleaved).
  * pivot_tau: 1.0 = partial pivoting on |re|+|im| (LAPACK zgetrf's choice); 0 < tau < 1 keeps the diagonal
- * pivot whenever it is within a factor tau of the column maximum.  info: [item*F + f]. */
+ * pivot whenever it is within a factor tau of the column maximum.  info: [item*F + f].
+ * ws: caller-owned scratch of hmv_tf_workspace_doubles(n_items, m, p) doubles (the coefficients re-ordered
+ * once per item so that every per-frequency read is fully coalesced). */
+int64_t hmv_tf_workspace_doubles(int64_t n_items, int m, int p);
 int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F,
                double* P, double* rowsum, double* H, double* A, int32_t* info,
-               double pivot_tau, void* stream);
+               double pivot_tau, double* ws, void* stream);
 
 /* K4.  out[item][i][j][f] = P[item][f][i][j] / sum_{j',f'} P[item][f'][i][j']   (normalise = 1)
  * Replaces the normalisation loop of full_freq_dtf (src/mtmvar.py:281-283); normalise = 0 returns the

@@ -45,7 +45,8 @@ def test_argument_checks_without_gpu(lib):
     assert b"channel count" in lib.hmv_last_error()
     assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 8, 100, 40, 0, 0) == -2
     assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 8, 4, 4, 0, 0) == -3
-    assert lib.hmv_tf_f64(1, 1, 8, 2, 1, 4, 0, 0, 0, 0, 1, 1.5, 0) == -6
+    assert lib.hmv_tf_f64(1, 1, 8, 2, 1, 4, 0, 0, 0, 0, 1, 1.5, 1, 0) == -6
+    assert lib.hmv_tf_workspace_doubles(3, 20, 5) == 3 * 32 * 32 * 6
 
 
 def test_product_does_not_import_oracle_or_fall_back():

@@ -23,12 +23,13 @@ ar, V, _, info = eng.yw_solve(R, m)
 tw = eng.twiddles(0.5 * np.arange(1, F + 1), 500.0, p)
 P = torch.empty(n_items, F, 64, 64, dtype=torch.float64, device=dev); rs = torch.empty(n_items, F, 64, dtype=torch.float64, device=dev)
 inf = torch.zeros(n_items * F, dtype=torch.int32, device=dev)
+wsx = torch.empty(int(lib.hmv_tf_workspace_doubles(n_items, m, p)), dtype=torch.float64, device=dev)
 stamps = torch.zeros(n_items * F * 4, 8, dtype=torch.int64, device=dev)
 lib.hmv_debug_set_tf_stamps(stamps.data_ptr())
 for rep in range(2):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    rc = lib.hmv_tf_f64(ar.data_ptr(), n_items, m, p, tw.data_ptr(), F, P.data_ptr(), rs.data_ptr(), 0, 0, inf.data_ptr(), 1.0, 0)
+    rc = lib.hmv_tf_f64(ar.data_ptr(), n_items, m, p, tw.data_ptr(), F, P.data_ptr(), rs.data_ptr(), 0, 0, inf.data_ptr(), 1.0, wsx.data_ptr(), 0)
     e1.record(); torch.cuda.synchronize()
     assert rc == 0
 print("stamped kernel ms:", e0.elapsed_time(e1), "(do not quote: stamps serialise)")
