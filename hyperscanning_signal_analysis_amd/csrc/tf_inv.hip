@@ -12,28 +12,30 @@
 //
 // Design:
 //   * One workgroup of NT waves (MP = 16*NT <= 64 channels) owns one (window, frequency) matrix.  Wave w
-//     holds the 16 columns 16w..16w+15 of the MP x MP complex matrix in registers with the four blocks of
-//     the 4x4x4 MFMA on four ROW blocks (lane (i, b, j) holds rows 16*Ig+4*b+i, columns 16w+4*Jl+j in
-//     register [Ig][Jl]), so ONE column block (= one pivot panel) can be updated by 4*NT MFMAs on its own:
-//     64 VGPRs at MP = 64, four workgroups resident per CU, four waves per SIMD to issue from while
-//     others wait on LDS, global memory or a barrier.
-//   * Inversion = in-place blocked Gauss-Jordan, 4 pivot columns per block step s:
-//       1. the wave that owns the panel columns (w = s / 4) moves them through LDS into a lane-per-row
-//          layout (64 rows = 64 lanes) and runs the four pivot steps: wave-wide arg-max of |re|+|im|
-//          (LAPACK izamax metric; optional threshold tau), row interchange, complex reciprocal, elimination
-//          inside the panel.  Pivot rows are broadcast through LDS, not v_readlane (10 cycles of VALU
-//          each).  Result: N = M'[:, S] in LDS plus the four interchange indices,
-//       2. workgroup barrier,
-//       3. every wave applies the interchanges to its own columns (rare; through LDS), then runs the rank-4
-//          update  M <- M + (N - E_S) * M[S, :]  of its column group on the matrix pipe: A operand
-//          (N - E_S) from LDS (NT reads per wave), B operand M[S, :] by one ds_bpermute inside the 16-lane
-//          row; the owner skips its own panel block (it is overwritten with N),
-//       4. the owner overwrites the panel columns with N and goes straight on to the next panel (its own
-//          column group is up to date) while the other waves finish: a natural one-step look-ahead.
+//     holds the four 4-column blocks w, w+NT, w+2NT, w+3NT (block-cyclic) of the MP x MP complex matrix in
+//     registers with the four blocks of the 4x4x4 MFMA on four ROW blocks (lane (i, b, j) holds rows
+//     16*Ig+4*b+i, columns 4*(Jl*NT+w)+j in register [Ig][Jl]), so ONE column block (= one pivot panel) can
+//     be updated by 4*NT MFMAs on its own: 64 accumulator VGPRs at MP = 64, four workgroups resident per CU.
+//   * Inversion = in-place blocked Gauss-Jordan, 4 pivot columns per block step s, with a one-step
+//     look-ahead.  Panel s is column block s: owner wave s % NT, register block s / NT, so the ownership
+//     rotates every step.  During step s (N_s = M'[:, S_s] is in LDS):
+//       - the NEXT owner applies update s to its panel block only (4*NT MFMAs), moves the block through LDS
+//         into a lane-per-row layout (64 rows = 64 lanes) and runs the four pivot steps of panel s+1:
+//         wave-wide arg-max of |re|+|im| (LAPACK izamax metric; optional threshold tau), row interchange,
+//         complex reciprocal, elimination inside the panel; the pivot row is broadcast through LDS, not
+//         v_readlane.  It publishes N_{s+1} and the interchange list and DEFERS update s of its other three
+//         blocks to the start of step s+1 (N_s stays valid in a ring of three buffers),
+//       - the other waves apply the interchanges of step s (rare; through LDS) and the rank-4 update
+//         M <- M + (N_s - E_S) * M[S, :] of their four blocks on the matrix pipe (A operand from LDS, B operand
+//         = the pivot rows by one ds_bpermute inside the 16-lane row); the owner of panel s replaces its
+//         panel block by N_s instead of updating it,
+//       - one workgroup barrier per step.
+//     The serial factorisation (the critical path) thus overlaps the other waves' MFMA work, and every wave
+//     runs one factorisation in NT steps.
 //     Row interchanges leave the inverse with permuted columns; `orig[c]` (LDS) tracks which original row
 //     sits in row c and the output column of stored column c is orig[c].
-//   * A(f) is assembled from the AR coefficients ([row][col][lag], lag fastest = the reference's own
-//     (m, m, p) layout) with batched 16-byte loads that hit L2.
+//   * A(f) is assembled from the AR coefficients re-packed once per item into this register order
+//     (ar_pack_kernel), so every per-frequency read is a fully coalesced 16-byte load.
 //
 // Outputs (all optional):  P[item][f][row][col] = |H|^2 (scratch layout, transposed to (m, m, F) by K4),
 // rowsum[item][f][row] = sum_col |H|^2, H / A as interleaved complex128 [item][f][row][col].
@@ -67,27 +69,29 @@ namespace hmv {
 template <int NT>
 struct TfLds {
   static constexpr int MP = 16 * NT;
+  static constexpr int NRING = 3;            // N_s is read during steps s and s+1, N_{s+1} written during s
   // double2 units
   static constexpr int PBUF = MP * 5;        // panel, row stride 80 B (conflict-free lane-per-row reads)
-  static constexpr int NBUF = MP * 4;        // N = M'[:, S], row stride 64 B; two buffers (look-ahead)
+  static constexpr int NBUF = MP * 4;        // N = M'[:, S], row stride 64 B
   static constexpr int SROW = 8;             // pivot row + displaced row of the current pivot column
   static constexpr int SWAPB = NT * 32;      // per wave: two matrix-row segments of 16 columns
   static constexpr int RSUM = NT * MP / 2;   // per wave row-sum partials (doubles)
-  static constexpr int TOTAL = PBUF + 2 * NBUF + SROW + SWAPB + RSUM;
+  static constexpr int TOTAL = PBUF + NRING * NBUF + SROW + SWAPB + RSUM;
 };
 
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfArgs a) {
   constexpr int MP = 16 * NT, NG = NT, NSTEP = MP / 4;
   using L = TfLds<NT>;
+  constexpr int NR = L::NRING;
   __shared__ double2 smem[L::TOTAL];
   __shared__ int s_orig[MP];
-  __shared__ __attribute__((aligned(16))) int s_swp[2][4];
+  __shared__ __attribute__((aligned(16))) int s_swp[NR][4];
   __shared__ int s_info;
 
   const int l = lane_id();
   const int wv = uni(threadIdx.x >> 6);         // hardware wave index inside the workgroup
-  // Column group owned by this wave, rotated per workgroup by a hash of the block id: co-resident
+  // Column blocks owned by this wave, rotated per workgroup by a hash of the block id: co-resident
   // workgroups run in near lockstep and wave k of every workgroup tends to sit on the same SIMD, so without
   // the rotation the resident panel factorisations (one wave each) pile up on one SIMD.
   const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;
@@ -96,14 +100,14 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   const int f = uni((int)(blockIdx.x - (unsigned)item * (unsigned)a.F));
   const int p = a.p;
   // "X layout" (hmv_common.h lane maps with the four MFMA blocks on four ROW blocks): lane (i, b, j) holds
-  // rows 16*Ig + 4*b + i and columns col0 + 4*Jl + j in register [Ig][Jl].
+  // rows 16*Ig + 4*b + i and columns 4*(Jl*NT + w) + j in register [Ig][Jl].
   const int i = l >> 4, b = (l >> 2) & 3, j = l & 3;
   const int rowl = 4 * b + i;                   // row inside a 16-row group
-  const int col0 = 16 * w;
+  const int colw = 4 * w + j;                   // column inside a group of 4*NT columns
 
   double2* Pbuf = smem;
   double2* Nbuf = Pbuf + L::PBUF;
-  double2* Srow = Nbuf + 2 * L::NBUF;
+  double2* Srow = Nbuf + NR * L::NBUF;
   double2* swapb = Srow + L::SROW + wv * 32;
   double* rsum = reinterpret_cast<double*>(Srow + L::SROW + L::SWAPB);
 
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     for (int Ig = 0; Ig < NG; ++Ig)
 #pragma unroll
       for (int Jl = 0; Jl < 4; ++Jl) {
-        re[Ig][Jl] = (16 * Ig + rowl == col0 + 4 * Jl + j) ? 1.0 : 0.0;
+        re[Ig][Jl] = (16 * Ig + rowl == 4 * NT * Jl + colw) ? 1.0 : 0.0;
         im[Ig][Jl] = 0.0;
       }
     // Chunks of HC lag pairs; a batch (two column blocks of one row group) issues all of its loads before
@@ -170,11 +174,12 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     for (; h0 + 4 <= P2; h0 += 4) chunk(std::integral_constant<int, 4>{}, h0);
     for (; h0 < P2; ++h0) chunk(std::integral_constant<int, 1>{}, h0);
     if (a.A) {
-      double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP + (size_t)rowl * MP + col0 + j;
+      double2* Ao = reinterpret_cast<double2*>(a.A) + (size_t)gw * MP * MP + (size_t)rowl * MP + colw;
 #pragma unroll
       for (int Ig = 0; Ig < NG; ++Ig)
 #pragma unroll
-        for (int Jl = 0; Jl < 4; ++Jl) Ao[(size_t)(16 * Ig) * MP + 4 * Jl] = make_double2(re[Ig][Jl], im[Ig][Jl]);
+        for (int Jl = 0; Jl < 4; ++Jl)
+          Ao[(size_t)(16 * Ig) * MP + 4 * NT * Jl] = make_double2(re[Ig][Jl], im[Ig][Jl]);
     }
   }
   if (w == 0) {
@@ -184,137 +189,154 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   const double tau = a.tau;
   HMV_T(0);
 
-  // ---------------------------------------------------------------- blocked Gauss-Jordan
-  static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int ws = s >> 2;        // owner wave (column group) AND 16-row group of the pivot rows 4s..4s+3
-    constexpr int q = s & 3;          // column block of the panel inside the owner, and b of the pivot rows
-    double2* Ncur = Nbuf + (s & 1) * L::NBUF;
-    HMV_T(5);
-
-    if (w == ws) {
-      // ---- 1. panel -> LDS -> lane-per-row, four pivot steps (this wave only).  The factorisation is the
-      // workgroup's critical path (the other waves wait for it), so it outranks the other workgroups' MFMA
-      // work on this SIMD.
-      __builtin_amdgcn_s_setprio(3);
+  // ---------------------------------------------------------------- building blocks
+  // Panel t (columns 4t..4t+3) = register block J of its owner: -> LDS -> lane-per-row, four pivot steps,
+  // N_t and the interchange list -> LDS.  Runs on ONE wave; it is the workgroup's critical path, so it
+  // outranks the other workgroups' MFMA work on this SIMD.
+  auto factor_panel = [&](auto tc, auto jc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, J = decltype(jc)::value;
+    double2* Nout = Nbuf + (t % NR) * L::NBUF;
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-      for (int Ig = 0; Ig < NG; ++Ig) Pbuf[(16 * Ig + rowl) * 5 + j] = make_double2(re[Ig][q], im[Ig][q]);
-      HMV_LDS_FENCE();
-      double2 x[4];     // (re, im) adjacent: LDS transfers need no register shuffling
-      {
-        const int r = (l < MP) ? l : 0;
+    for (int Ig = 0; Ig < NG; ++Ig) Pbuf[(16 * Ig + rowl) * 5 + j] = make_double2(re[Ig][J], im[Ig][J]);
+    HMV_LDS_FENCE();
+    double2 x[4];     // (re, im) adjacent: LDS transfers need no register shuffling
+    {
+      const int r = (l < MP) ? l : 0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
+      for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int col = 4 * t + jj;
+      const bool valid = (l >= col) && (l < MP);
+      // arg-max of |re|+|im| (LAPACK izamax metric) over the not-yet-pivoted rows: float-rounded magnitude
+      // as a 32-bit key (monotonic for non-negative floats), DPP max, lowest lane holding the maximum.
+      const float candf = (float)(__builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y));
+      const unsigned key = valid ? __float_as_uint(candf) : 0u;
+      const unsigned kmax = wave_max_u32(key);
+      int rstar = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(valid && key == kmax));
+      if (tau < 1.0) {   // threshold pivoting: keep the diagonal when it is within tau of the maximum
+        const double cand = __builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y);
+        const double vmax = readlane_f64(cand, rstar), dc = readlane_f64(cand, col);
+        if (dc >= tau * vmax) rstar = col;
       }
+      // pivot element by v_readlane (the reciprocal chain starts at once); the pivot row -- and, on an
+      // interchange, the displaced row -- go through LDS and are broadcast to every lane
+      const double pr = readlane_f64(x[jj].x, rstar), pi = readlane_f64(x[jj].y, rstar);
+      if (l == rstar) {
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int col = 4 * s + jj;
-        const bool valid = (l >= col) && (l < MP);
-        // arg-max of |re|+|im| (LAPACK izamax metric) over the not-yet-pivoted rows: float-rounded magnitude
-        // as a 32-bit key (monotonic for non-negative floats), DPP max, lowest lane holding the maximum.
-        const float candf = (float)(__builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y));
-        const unsigned key = valid ? __float_as_uint(candf) : 0u;
-        const unsigned kmax = wave_max_u32(key);
-        int rstar = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(valid && key == kmax));
-        if (tau < 1.0) {   // threshold pivoting: keep the diagonal when it is within tau of the maximum
-          const double cand = __builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y);
-          const double vmax = readlane_f64(cand, rstar), dc = readlane_f64(cand, col);
-          if (dc >= tau * vmax) rstar = col;
+        for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
+      }
+      if (rstar != col) {          // uniform
+        if (l == col) {
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
         }
-        // pivot element by v_readlane (the reciprocal chain starts at once); the pivot row -- and, on an
-        // interchange, the displaced row -- go through LDS and are broadcast to every lane
-        const double pr = readlane_f64(x[jj].x, rstar), pi = readlane_f64(x[jj].y, rstar);
-        if (l == rstar) {
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
+        if (l == 0) {
+          const int oc = s_orig[col], orr = s_orig[rstar];
+          s_orig[col] = orr;
+          s_orig[rstar] = oc;
         }
-        if (rstar != col) {          // uniform
-          if (l == col) {
+      }
+      if (l == 0) s_swp[t % NR][jj] = rstar;
+      const double dd = __builtin_fma(pr, pr, pi * pi);
+      if (!(dd > 0.0) && l == 0 && s_info == 0) s_info = col + 1;
+      double invd = __builtin_amdgcn_rcp(dd);                    // v_rcp_f64 seed + 2 Newton steps
+      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
+      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
+      const double ivr = pr * invd, ivi = -pi * invd;
+      HMV_LDS_FENCE();
+      double2 pv[4];
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
-          }
-          if (l == 0) {
-            const int oc = s_orig[col], orr = s_orig[rstar];
-            s_orig[col] = orr;
-            s_orig[rstar] = oc;
-          }
-        }
-        if (l == 0) s_swp[s & 1][jj] = rstar;
-        const double dd = __builtin_fma(pr, pr, pi * pi);
-        if (!(dd > 0.0) && l == 0 && s_info == 0) s_info = col + 1;
-        double invd = __builtin_amdgcn_rcp(dd);                    // v_rcp_f64 seed + 2 Newton steps
-        invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
-        invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
-        const double ivr = pr * invd, ivi = -pi * invd;
-        HMV_LDS_FENCE();
-        double2 pv[4];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) pv[j2] = Srow[j2];
-        if (rstar != col) {          // uniform: the lane that held the pivot row takes the displaced row
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) {
-            const double2 cv = Srow[4 + j2];
-            x[j2].x = (l == rstar) ? cv.x : x[j2].x;
-            x[j2].y = (l == rstar) ? cv.y : x[j2].y;
-          }
-        }
-        HMV_LDS_FENCE();
-        // Elimination with the per-row multiplier mu = -x_jj / pivot:  x <- x + mu * (pivot row), and column
-        // jj becomes mu itself (in-place inverse).  The pivot row's lane takes mu = 1/pivot on a zeroed row,
-        // which yields the scaled pivot row and 1/pivot in column jj from the same FMAs: no per-element
-        // selects and no separately scaled pivot row (27 VALU ops per column instead of 44).
-        const bool isp = (l == col);
-        const double fr = x[jj].x, fi = x[jj].y;
-        double mr = __builtin_fma(fi, ivi, -(fr * ivr));
-        double mi = __builtin_fma(-fr, ivi, -(fi * ivr));
-        mr = isp ? ivr : mr;
-        mi = isp ? ivi : mi;
-        const double keep = isp ? 0.0 : 1.0;
+      for (int j2 = 0; j2 < 4; ++j2) pv[j2] = Srow[j2];
+      if (rstar != col) {          // uniform: the lane that held the pivot row takes the displaced row
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
-          if (j2 == jj) continue;
-          const double br = x[j2].x * keep, bi = x[j2].y * keep;
-          x[j2].x = __builtin_fma(-mi, pv[j2].y, __builtin_fma(mr, pv[j2].x, br));
-          x[j2].y = __builtin_fma(mi, pv[j2].x, __builtin_fma(mr, pv[j2].y, bi));
+          const double2 cv = Srow[4 + j2];
+          x[j2].x = (l == rstar) ? cv.x : x[j2].x;
+          x[j2].y = (l == rstar) ? cv.y : x[j2].y;
         }
-        x[jj].x = mr;
-        x[jj].y = mi;
       }
-      if (l < MP) {
+      HMV_LDS_FENCE();
+      // Elimination with the per-row multiplier mu = -x_jj / pivot:  x <- x + mu * (pivot row), and column
+      // jj becomes mu itself (in-place inverse).  The pivot row's lane takes mu = 1/pivot on a zeroed row,
+      // which yields the scaled pivot row and 1/pivot in column jj from the same FMAs: no per-element
+      // selects and no separately scaled pivot row (27 VALU ops per column instead of 44).
+      const bool isp = (l == col);
+      const double fr = x[jj].x, fi = x[jj].y;
+      double mr = __builtin_fma(fi, ivi, -(fr * ivr));
+      double mi = __builtin_fma(-fr, ivi, -(fi * ivr));
+      mr = isp ? ivr : mr;
+      mi = isp ? ivi : mi;
+      const double keep = isp ? 0.0 : 1.0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) Ncur[l * 4 + jj] = x[jj];
+      for (int j2 = 0; j2 < 4; ++j2) {
+        if (j2 == jj) continue;
+        const double br = x[j2].x * keep, bi = x[j2].y * keep;
+        x[j2].x = __builtin_fma(-mi, pv[j2].y, __builtin_fma(mr, pv[j2].x, br));
+        x[j2].y = __builtin_fma(mi, pv[j2].x, __builtin_fma(mr, pv[j2].y, bi));
       }
-      HMV_T(1);
+      x[jj].x = mr;
+      x[jj].y = mi;
     }
-    // The wave that factors the NEXT panel stays at high priority through its own update as well: panel
-    // factorisation -> update of the owner's columns -> next factorisation is the workgroup's critical path.
-    if (s + 1 < NSTEP && w == ((s + 1) >> 2)) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
-    __syncthreads();   // ---- 2. N, the interchange list and orig[] are visible to every wave
-
-    HMV_T(2);
-    // ---- 3a. pending row interchanges on this wave's columns
-    // A operands (N - E_S, rows 16*Ig + (l & 15), k = l >> 4) and the interchange list: one LDS round trip
-    double2 nv[NG];
+    if (l < MP) {
 #pragma unroll
-    for (int Ig = 0; Ig < NG; ++Ig) nv[Ig] = Ncur[(16 * Ig + (l & 15)) * 4 + (l >> 4)];
-    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[s & 1][0]);
+      for (int jj = 0; jj < 4; ++jj) Nout[l * 4 + jj] = x[jj];
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // A operands of update t: (N_t - E_S) rows 16*Ig + (l & 15), k = l >> 4 (one LDS round trip)
+  auto load_n = [&](auto tc, double (&nr)[NG], double (&ni)[NG]) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
+    const double2* Nt = Nbuf + (t % NR) * L::NBUF;
+    const double dlt = (b == (t & 3) && j == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig) {
+      const double2 v = Nt[(16 * Ig + (l & 15)) * 4 + (l >> 4)];
+      nr[Ig] = (Ig == (t >> 2)) ? v.x - dlt : v.x;
+      ni[Ig] = v.y;
+    }
+  };
+  // Rank-4 update t of register block J on the matrix pipe.  B operand: pivot row 4t+k at this lane's
+  // column, held by lane (i = k, b = t & 3, j) in register [t >> 2][J] -> one bpermute inside the 16-lane row.
+  auto update_block = [&](auto tc, auto jc, const double (&nr)[NG], const double (&ni)[NG])
+                          __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, J = decltype(jc)::value;
+    const int bsrc = (l & 0x33) | ((t & 3) << 2);
+    const double ur = shfl_f64(re[t >> 2][J], bsrc), ui = shfl_f64(im[t >> 2][J], bsrc);
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig) {
+      re[Ig][J] = mfma4(nr[Ig], ur, re[Ig][J]);
+      im[Ig][J] = mfma4(nr[Ig], ui, im[Ig][J]);
+    }
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig) {
+      re[Ig][J] = mfma4_nega(ni[Ig], ui, re[Ig][J]);     // re -= ni * ui (NEG modifier)
+      im[Ig][J] = mfma4(ni[Ig], ur, im[Ig][J]);
+    }
+  };
+  // Row interchanges of step t on this wave's 16 columns (rare; through LDS).
+  auto interchange = [&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, Igp = t >> 2, bp = t & 3;
+    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[t % NR][0]);
     const int swr[4] = {uni(swv.x), uni(swv.y), uni(swv.z), uni(swv.w)};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const int col = 4 * s + jj;
+      const int col = 4 * t + jj;
       const int rstar = swr[jj];
       if (rstar != col) {
-        // row `col` = (Ig ws, b q, i jj); row rstar = (Ig rstar>>4, b (rstar>>2)&3, i rstar&3)
+        // row `col` = (Ig Igp, b bp, i jj); row rstar = (Ig rstar>>4, b (rstar>>2)&3, i rstar&3)
         const int Igs = rstar >> 4, bs = (rstar >> 2) & 3, is = rstar & 3;
-        if (i == jj && b == q) {
+        if (i == jj && b == bp) {
 #pragma unroll
-          for (int Jl = 0; Jl < 4; ++Jl) swapb[Jl * 4 + j] = make_double2(re[ws][Jl], im[ws][Jl]);
+          for (int Jl = 0; Jl < 4; ++Jl) swapb[Jl * 4 + j] = make_double2(re[Igp][Jl], im[Igp][Jl]);
         }
         HMV_LDS_FENCE();
         // expanded at compile time (a run-time loop here is folded into re[Igs], i.e. scratch)
-        static_for<NG - ws>([&](auto ic) __attribute__((always_inline)) {
-          constexpr int Ig = ws + decltype(ic)::value;
+        static_for<NG - Igp>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int Ig = Igp + decltype(ic)::value;
           if (Ig == Igs) {
             if (i == is && b == bs) {
 #pragma unroll
@@ -329,56 +351,83 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
           }
         });
         HMV_LDS_FENCE();
-        if (i == jj && b == q) {
+        if (i == jj && b == bp) {
 #pragma unroll
           for (int Jl = 0; Jl < 4; ++Jl) {
             const double2 v = swapb[16 + Jl * 4 + j];
-            re[ws][Jl] = v.x;
-            im[ws][Jl] = v.y;
+            re[Igp][Jl] = v.x;
+            im[Igp][Jl] = v.y;
           }
         }
         HMV_LDS_FENCE();
       }
     }
-    HMV_T(3);
-    // ---- 3b. rank-4 update of this wave's 16 columns on the matrix pipe.  B operand: pivot row 4s+k at
-    // this lane's column, held by lane (i = k, b = q, j) in register [ws][Jl] -> one bpermute inside the
-    // 16-lane row; A operand: nv (minus the identity on the pivot rows).
-    const int bsrc = (l & 0x33) | (q << 2);
-    double ur[4], ui[4];
+  };
+  // panel block <- N_t (owner of panel t)
+  auto take_panel = [&](auto tc, auto jc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value, J = decltype(jc)::value;
+    const double2* Nt = Nbuf + (t % NR) * L::NBUF;
 #pragma unroll
-    for (int Jl = 0; Jl < 4; ++Jl) {
-      ur[Jl] = shfl_f64(re[ws][Jl], bsrc);
-      ui[Jl] = shfl_f64(im[ws][Jl], bsrc);
+    for (int Ig = 0; Ig < NG; ++Ig) {
+      const double2 v = Nt[(16 * Ig + rowl) * 4 + j];
+      re[Ig][J] = v.x;
+      im[Ig][J] = v.y;
     }
-    const double dlt = (b == q && j == i) ? 1.0 : 0.0;
+  };
+
+  // ---------------------------------------------------------------- blocked Gauss-Jordan
+  if (w == 0) factor_panel(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  HMV_T(1);
+  __syncthreads();
+  HMV_T(2);
+  static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int own = s % NT, Js = s / NT;                      // owner wave / register block of panel s
+    constexpr bool has_next = (s + 1 < NSTEP);
+    constexpr int nxt = (s + 1) % NT, Jn = has_next ? (s + 1) / NT : 0;
+    // Every update is a guarded slot of one register block in straight-line code (wave-uniform guards):
+    // large if/else bodies that each rewrite many accumulators make the register allocator copy and spill.
+    // ---- A. the owner of panel s factored it during step s-1 and deferred update s-1 of its other blocks
+    if constexpr (s >= 1) {
+      constexpr int t = s - 1;
+      double ar_[NG], ai_[NG];
 #pragma unroll
-    for (int Jl = 0; Jl < 4; ++Jl) {
-      // the owner's own panel block is overwritten with N below: its MFMAs would be wasted
-      if (w != ws || Jl != q) {
-#pragma unroll
-        for (int Ig = 0; Ig < NG; ++Ig) {
-          const double ar_ = (Ig == ws) ? nv[Ig].x - dlt : nv[Ig].x;
-          re[Ig][Jl] = mfma4(ar_, ur[Jl], re[Ig][Jl]);
-          im[Ig][Jl] = mfma4(ar_, ui[Jl], im[Ig][Jl]);
+      for (int Ig = 0; Ig < NG; ++Ig) ar_[Ig] = ai_[Ig] = 0.0;
+      if (w == own) load_n(std::integral_constant<int, t>{}, ar_, ai_);
+      static_for<4>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int Jl = decltype(jc)::value;
+        // not its panel block (updated before the factorisation), nor panel block t itself (NT == 1)
+        if constexpr (Jl != Js && !(NT == 1 && Jl == t / NT)) {
+          if (w == own) update_block(std::integral_constant<int, t>{}, jc, ar_, ai_);
         }
-#pragma unroll
-        for (int Ig = 0; Ig < NG; ++Ig) {
-          re[Ig][Jl] = mfma4_nega(nv[Ig].y, ui[Jl], re[Ig][Jl]);     // re -= ni * ui (NEG modifier)
-          im[Ig][Jl] = mfma4(nv[Ig].y, ur[Jl], im[Ig][Jl]);
-        }
-      }
+      });
     }
     HMV_T(4);
-    // ---- 4. panel columns <- N (owner wave)
-    if (w == ws) {
-#pragma unroll
-      for (int Ig = 0; Ig < NG; ++Ig) {
-        const double2 v = Ncur[(16 * Ig + rowl) * 4 + j];
-        re[Ig][q] = v.x;
-        im[Ig][q] = v.y;
+    __builtin_amdgcn_sched_barrier(0);     // keep the next operand loads below the deferred MFMAs (VGPR budget)
+    // ---- B. interchanges of step s, A operands of update s
+    double nr[NG], ni[NG];
+    load_n(sc, nr, ni);
+    interchange(sc);
+    HMV_T(3);
+    // ---- C. update s.  The next owner does its panel block only, then factors panel s+1; the owner of
+    // panel s replaces its panel block by N_s.
+    const bool is_nxt = has_next && (w == nxt);
+    if (w == own) take_panel(sc, std::integral_constant<int, Js>{});
+    if (is_nxt || !(w == own && Jn == Js)) update_block(sc, std::integral_constant<int, Jn>{}, nr, ni);
+    static_for<4>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int Jl = decltype(jc)::value;
+      if constexpr (Jl != Jn) {
+        if (!is_nxt && !(w == own && Jl == Js)) update_block(sc, jc, nr, ni);
       }
-    }
+    });
+    HMV_T(4);
+    __builtin_amdgcn_sched_barrier(0);
+    // last in program order (the next owner skipped the slots above): the A operands are dead here, the
+    // factorisation runs with only the accumulators live
+    if (is_nxt) factor_panel(std::integral_constant<int, s + 1>{}, std::integral_constant<int, Jn>{});
+    HMV_T(1);
+    __syncthreads();
+    HMV_T(2);
   });
 
   HMV_T(5);
@@ -390,7 +439,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   const int rowo = 4 * ((lo >> 2) & 3) + (lo >> 4), jo = lo & 3;
   int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
 #pragma unroll
-  for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[16 * w + 4 * Jl + jo];
+  for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[4 * (Jl * NT + w) + jo];
   if (w == 0 && lo == 0) a.info[gw] = s_info;
 
   if (a.H) {
@@ -434,7 +483,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 
 // ---------------------------------------------------------------- coefficient packing
 // ar (reference layout [item][row][col][lag], rows/cols padded to MP) -> arx[item][w][Ig][Jl][h][lane][2]:
-// lane (i, b, j) of wave w finds lags (2h, 2h+1) of element (16*Ig + 4*b + i, 16*w + 4*Jl + j) at its own
+// lane (i, b, j) of wave w finds lags (2h, 2h+1) of element (16*Ig + 4*b + i, 4*(Jl*NT + w) + j) at its own
 // 16-byte slot (zero for the padding lag of an odd order).  262 KB per item, once per item instead of once
 // per (item, frequency).
 template <int NT>
@@ -451,7 +500,7 @@ __global__ void __launch_bounds__(256) ar_pack_kernel(const double* ar, double* 
   const int Jl = (int)(r & 3); r >>= 2;
   const int Ig = (int)(r % NT);
   const int w = (int)(r / NT);
-  const int row = 16 * Ig + 4 * ((lane >> 2) & 3) + (lane >> 4), col = 16 * w + 4 * Jl + (lane & 3);
+  const int row = 16 * Ig + 4 * ((lane >> 2) & 3) + (lane >> 4), col = 4 * (Jl * NT + w) + (lane & 3);
   const double* e = ar + ((size_t)item * MP * MP + (size_t)row * MP + col) * p;
   double2 v;
   v.x = e[2 * h];
