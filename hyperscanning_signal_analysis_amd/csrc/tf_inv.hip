@@ -210,16 +210,17 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * t + jj;
       const bool valid = (l >= col) && (l < MP);
-      // arg-max of |re|+|im| (LAPACK izamax metric) over the not-yet-pivoted rows: float-rounded magnitude
-      // as a 32-bit key (monotonic for non-negative floats), DPP max, lowest lane holding the maximum.
-      const float candf = (float)(__builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y));
-      const unsigned key = valid ? __float_as_uint(candf) : 0u;
-      const unsigned kmax = wave_max_u32(key);
-      int rstar = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(valid && key == kmax));
-      if (tau < 1.0) {   // threshold pivoting: keep the diagonal when it is within tau of the maximum
-        const double cand = __builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y);
-        const double vmax = readlane_f64(cand, rstar), dc = readlane_f64(cand, col);
-        if (dc >= tau * vmax) rstar = col;
+      // Pivot = arg-max of |re|+|im| (LAPACK izamax metric) over the not-yet-pivoted rows, or the diagonal
+      // when it is within tau of the maximum.  Fast path: no row exceeds the diagonal (one compare + ballot;
+      // the common case for the A(f) of a stable model).  Otherwise the float-rounded magnitude is a 32-bit
+      // key (monotonic for non-negative floats): DPP max, lowest lane holding the maximum.
+      const double cand = __builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y);
+      const double dc = readlane_f64(cand, col);
+      int rstar = col;
+      if (__builtin_amdgcn_ballot_w64(valid && (tau * cand > dc)) != 0ull) {
+        const unsigned key = valid ? __float_as_uint((float)cand) : 0u;
+        const unsigned kmax = wave_max_u32(key);
+        rstar = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(valid && key == kmax));
       }
       // pivot element by v_readlane (the reciprocal chain starts at once); the pivot row -- and, on an
       // interchange, the displaced row -- go through LDS and are broadcast to every lane
