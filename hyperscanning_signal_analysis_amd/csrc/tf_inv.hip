@@ -386,6 +386,8 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     constexpr int own = s % NT, Js = s / NT;                      // owner wave / register block of panel s
     constexpr bool has_next = (s + 1 < NSTEP);
     constexpr int nxt = (s + 1) % NT, Jn = has_next ? (s + 1) / NT : 0;
+    // The next owner carries the workgroup's critical path from this barrier to the end of its factorisation.
+    if (has_next && w == nxt) __builtin_amdgcn_s_setprio(3);
     // Every update is a guarded slot of one register block in straight-line code (wave-uniform guards):
     // large if/else bodies that each rewrite many accumulators make the register allocator copy and spill.
     // ---- A. the owner of panel s factored it during step s-1 and deferred update s-1 of its other blocks
