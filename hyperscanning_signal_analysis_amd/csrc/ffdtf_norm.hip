@@ -20,7 +20,15 @@ __global__ void __launch_bounds__(64) den_kernel(const double* rowsum, double* d
   if (i >= m_pad) return;
   const double* rs = rowsum + (size_t)item * F * m_pad + i;
   double acc = 0.0;
-  for (int f = 0; f < F; ++f) acc += rs[(size_t)f * m_pad];
+  int f = 0;
+  for (; f + 16 <= F; f += 16) {          // 16 loads in flight, summed in the fixed order f = 0, 1, 2, ...
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = rs[(size_t)(f + k) * m_pad];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += v[k];
+  }
+  for (; f < F; ++f) acc += rs[(size_t)f * m_pad];
   den[(size_t)item * m_pad + i] = acc;
 }
 
@@ -37,25 +45,27 @@ __global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
   const int f0 = (int)(tile_id % nft) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const double* P = a.P + ((size_t)item * F * MP + (size_t)i) * MP;   // + f*MP*MP + j
-  // read: rows f, columns j (contiguous)
-#pragma unroll 4
-  for (int r = ty; r < 64; r += 4) {
-    const int f = f0 + r;
-    double v = 0.0;
-    if (f < F && tx < m) v = P[(size_t)f * MP * MP + tx];
-    tile[r][tx] = v;
+  // read: rows f, columns j (contiguous); all 16 loads of a thread in flight before the first LDS write
+  // (the kernel is bound by bytes in flight: 4 workgroups x 32 KB per CU cover the HBM latency)
+  double stage[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int f = f0 + ty + 4 * k;
+    stage[k] = (f < F && tx < m) ? __builtin_nontemporal_load(P + (size_t)f * MP * MP + tx) : 0.0;
   }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = stage[k];
   __syncthreads();
   double scale_den = 1.0;
   if (a.normalise) scale_den = a.den[(size_t)item * MP + i];
   double* out = a.out + (((size_t)item * m + i) * m) * F;             // + j*F + f
-#pragma unroll 4
+#pragma unroll
   for (int r = ty; r < 64; r += 4) {
     const int j = r;
     const int f = f0 + tx;
     if (j < m && f < F) {
       const double v = tile[tx][j];
-      out[(size_t)j * F + f] = a.normalise ? v / scale_den : v;
+      __builtin_nontemporal_store(a.normalise ? v / scale_den : v, out + (size_t)j * F + f);
     }
   }
 }
