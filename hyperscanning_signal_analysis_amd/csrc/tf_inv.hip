@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
     }
+    int rs[4], bad = 0;      // pivot rows of the four columns, first zero pivot (+1): wave-uniform
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * t + jj;
@@ -215,43 +216,54 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       // the common case for the A(f) of a stable model).  Otherwise the float-rounded magnitude is a 32-bit
       // key (monotonic for non-negative floats): DPP max, lowest lane holding the maximum.
       const double cand = __builtin_fabs(x[jj].x) + __builtin_fabs(x[jj].y);
-      const double dc = readlane_f64(cand, col);
+      // The diagonal is read (v_readlane) and its reciprocal started at once, before the test resolves; an
+      // interchange (slow path) repeats both for the row it picks.  1/(pr + i pi) = (pr - i pi) / dd with
+      // 1/dd from the v_rcp_f64 seed (2^-24) and two Newton steps, the second folded into the products.
+      double pr = readlane_f64(x[jj].x, col), pi = readlane_f64(x[jj].y, col);
+      const double dc = __builtin_fabs(pr) + __builtin_fabs(pi);
+      const bool need_search = __builtin_amdgcn_ballot_w64(valid && (tau * cand > dc)) != 0ull;
+      double dd, ivr, ivi;
+      auto reciprocal = [&]() __attribute__((always_inline)) {
+        dd = __builtin_fma(pr, pr, pi * pi);
+        double y = __builtin_amdgcn_rcp(dd);
+        y = __builtin_fma(__builtin_fma(-dd, y, 1.0), y, y);
+        const double e = __builtin_fma(-dd, y, 1.0), tr = pr * y, ti = -pi * y;
+        ivr = __builtin_fma(tr, e, tr);
+        ivi = __builtin_fma(ti, e, ti);
+      };
+      reciprocal();
+      // Everything only an interchange needs (search, second reciprocal, displaced row, orig[]) sits behind
+      // one wave-uniform branch; the pivot row goes through LDS and is broadcast to every lane.
       int rstar = col;
-      if (__builtin_amdgcn_ballot_w64(valid && (tau * cand > dc)) != 0ull) {
+      if (__builtin_expect(need_search, 0)) {
         const unsigned key = valid ? __float_as_uint((float)cand) : 0u;
         const unsigned kmax = wave_max_u32(key);
         rstar = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(valid && key == kmax));
+        if (rstar != col) {
+          pr = readlane_f64(x[jj].x, rstar);
+          pi = readlane_f64(x[jj].y, rstar);
+          reciprocal();
+          if (l == col) {
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
+          }
+          if (l == 0) {
+            const int oc = s_orig[col], orr = s_orig[rstar];
+            s_orig[col] = orr;
+            s_orig[rstar] = oc;
+          }
+        }
       }
-      // pivot element by v_readlane (the reciprocal chain starts at once); the pivot row -- and, on an
-      // interchange, the displaced row -- go through LDS and are broadcast to every lane
-      const double pr = readlane_f64(x[jj].x, rstar), pi = readlane_f64(x[jj].y, rstar);
+      rs[jj] = rstar;
       if (l == rstar) {
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
       }
-      if (rstar != col) {          // uniform
-        if (l == col) {
-#pragma unroll
-          for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
-        }
-        if (l == 0) {
-          const int oc = s_orig[col], orr = s_orig[rstar];
-          s_orig[col] = orr;
-          s_orig[rstar] = oc;
-        }
-      }
-      if (l == 0) s_swp[t % NR][jj] = rstar;
-      const double dd = __builtin_fma(pr, pr, pi * pi);
-      if (!(dd > 0.0) && l == 0 && s_info == 0) s_info = col + 1;
-      double invd = __builtin_amdgcn_rcp(dd);                    // v_rcp_f64 seed + 2 Newton steps
-      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
-      invd = __builtin_fma(__builtin_fma(-dd, invd, 1.0), invd, invd);
-      const double ivr = pr * invd, ivi = -pi * invd;
       HMV_LDS_FENCE();
       double2 pv[4];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) pv[j2] = Srow[j2];
-      if (rstar != col) {          // uniform: the lane that held the pivot row takes the displaced row
+      if (__builtin_expect(rstar != col, 0)) {     // uniform: the lane that held the pivot row takes the displaced row
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
           const double2 cv = Srow[4 + j2];
@@ -260,6 +272,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         }
       }
       HMV_LDS_FENCE();
+      if (!(dd > 0.0) && bad == 0) bad = col + 1;      // wave-uniform
       // Elimination with the per-row multiplier mu = -x_jj / pivot:  x <- x + mu * (pivot row), and column
       // jj becomes mu itself (in-place inverse).  The pivot row's lane takes mu = 1/pivot on a zeroed row,
       // which yields the scaled pivot row and 1/pivot in column jj from the same FMAs: no per-element
@@ -284,6 +297,10 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     if (l < MP) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) Nout[l * 4 + jj] = x[jj];
+    }
+    if (l == 0) {
+      *reinterpret_cast<int4*>(&s_swp[t % NR][0]) = make_int4(rs[0], rs[1], rs[2], rs[3]);
+      if (bad != 0 && s_info == 0) s_info = bad;
     }
     __builtin_amdgcn_s_setprio(0);
   };
