@@ -12,7 +12,8 @@ for name, (res, args) in _lib.SIGNATURES.items():
     getattr(lib, name).restype = res; getattr(lib, name).argtypes = args
 lib.hmv_debug_set_tf_stamps.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
-n_items, m, p, F = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 64, 8, 256
+n_items, m, p = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 64, 8
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 # realistic AR coefficients: fit dyad 0 windows with the production library
 from hyperscanning_signal_analysis_amd.engine import Engine
 eng = Engine()
@@ -35,7 +36,7 @@ for rep in range(2):
 print("stamped kernel ms:", e0.elapsed_time(e1), "(do not quote: stamps serialise)")
 s = stamps.cpu().numpy().astype(np.float64)
 tot = s.sum(axis=1)
-names = ["A(f) build", "panel factor", "barrier wait", "interchanges", "MFMA update", "writeback+glue", "outputs", "-"]
+names = ["A(f) build", "panel: extract/search/recip", "barrier wait", "interchanges", "MFMA update", "panel: pivot row via LDS", "outputs", "panel: elimination"]
 print(f"cycles per wave life: median {np.median(tot):.0f}  mean {tot.mean():.0f}")
-for k in range(7):
-    print(f"  {names[k]:16s} median {np.median(s[:, k]):9.0f} cyc  share {s[:, k].sum() / tot.sum() * 100:5.1f} %")
+for k in range(8):
+    print(f"  {names[k]:28s} median {np.median(s[:, k]):9.0f} cyc  share {s[:, k].sum() / tot.sum() * 100:5.1f} %")
