@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--minutes", type=float, default=10.0, help="recording length per dyad (default 10)")
+    ap.add_argument("--single-stream", action="store_true", help="do not split K2 over two HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,12 +106,13 @@ def main():
         a.record(); b.record()
     torch.cuda.synchronize()
 
-    chunk = n_windows                       # one chunk per step: every kernel is launched once per step
+    chunk = n_windows                       # one chunk per step: K1, K3, K4 are launched once per step
     k3_windows = n_windows                  # windows of the K3 launch the events bracket
+    two_streams = not args.single_stream    # K2 as two half-batches on two HIP streams (library option)
 
     def step(k3_events=None):
         eng.sliding_ffdtf(x, item_rec, item_start, w, p, fdev, fs, out=out, check=False,
-                          chunk=chunk, k3_events=k3_events, overlap=False)
+                          chunk=chunk, k3_events=k3_events, overlap=two_streams)
 
     def barrier():
         if world > 1:
@@ -159,7 +161,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: 1 dyad/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
                                    "(%d windows), MVAR p=8, 256 freqs 0.5-128 Hz" % (args.minutes, n_windows),
-                       "windows_per_step_per_gpu": n_windows, "parallelism": f"dyad-sharded x{world}",
+                       "windows_per_step_per_gpu": n_windows, "k2_streams": 2 if two_streams else 1,
+                       "parallelism": f"dyad-sharded x{world}",
                        "gather": "band-integrated ffDTF to rank 0 (once, timed)" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4> (K3)", "achieved": achieved,
                          "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,

@@ -162,57 +162,62 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   if (!x || !item_rec || !item_start || !freqs || !ffdtf || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
   const SlidingWs w = sliding_layout(chunk, mp, p, F);
-  const int lanes = (aux_stream && aux_stream != stream && n_items > chunk) ? 2 : 1;
-  if ((int64_t)(w.total * lanes) > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
-  hipStream_t st[2] = {S(stream), S(aux_stream)};
+  if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
+  // Second stream: the Yule-Walker stage (K2) is a chain of ~25 launches of at most a few workgroups per
+  // window, two workgroups per CU -- 599 windows need 1.2 "rounds" of the chip per launch and leave most
+  // of it idle.  The windows are independent, so K2 runs as two half-batches, one per stream, whose launches
+  // interleave on the device (fork after K1, join before K3).  Chunk pipelining (K1/K2 of chunk c+1 under K3
+  // of chunk c) was measured and does NOT work: K3 holds every wave slot and starves the other stream.
+  hipStream_t st0 = S(stream), st1 = S(aux_stream);
+  const bool split = (aux_stream && aux_stream != stream);
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  if (lanes == 2) {
-    // fork: the auxiliary stream starts after everything already queued on the caller's stream
+  if (split) {
     if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
       return fail(-8, "hmv_sliding_ffdtf_f64: cannot create fork/join events");
-    (void)hipEventRecord(ev_fork, st[0]);
-    (void)hipStreamWaitEvent(st[1], ev_fork, 0);
   }
   int rc = 0;
   const size_t t = (size_t)mp * mp;
   const int64_t n_chunks = (n_items + chunk - 1) / chunk;
+  char* base = static_cast<char*>(workspace);
+  double* R = reinterpret_cast<double*>(base + w.off_R);
+  double* ws = reinterpret_cast<double*>(base + w.off_ws);
+  double* ar = reinterpret_cast<double*>(base + w.off_ar);
+  double* arx = reinterpret_cast<double*>(base + w.off_arx);
+  double* V = reinterpret_cast<double*>(base + w.off_V);
+  double* P = reinterpret_cast<double*>(base + w.off_P);
+  double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+  double* den = reinterpret_cast<double*>(base + w.off_den);
+  double* tw = reinterpret_cast<double*>(base + w.off_tw);
+  rc = hmv_twiddles_f64(freqs, F, fs, p, tw, st0);
+  const size_t ws_item = (size_t)hmv_yw_workspace_doubles(m, p);
   for (int64_t ci = 0; ci < n_chunks && rc == 0; ++ci) {
-    const int lane = (int)(ci % lanes);
-    void* s = st[lane];
-    char* base = static_cast<char*>(workspace) + (size_t)lane * w.total;
-    double* R = reinterpret_cast<double*>(base + w.off_R);
-    double* ws = reinterpret_cast<double*>(base + w.off_ws);
-    double* ar = reinterpret_cast<double*>(base + w.off_ar);
-    double* arx = reinterpret_cast<double*>(base + w.off_arx);
-    double* V = reinterpret_cast<double*>(base + w.off_V);
-    double* P = reinterpret_cast<double*>(base + w.off_P);
-    double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
-    double* den = reinterpret_cast<double*>(base + w.off_den);
-    double* tw = reinterpret_cast<double*>(base + w.off_tw);
-    if (ci < lanes) {                       // each lane keeps its own twiddle table: no cross-stream edge
-      rc = hmv_twiddles_f64(freqs, F, fs, p, tw, s);
-      if (rc) break;
-    }
     const int64_t i0 = ci * chunk;
     const int64_t c = (n_items - i0 < chunk) ? (n_items - i0) : chunk;
     double* ar_c = ar_out ? ar_out + (size_t)i0 * t * p : ar;
     double* V_c = V_out ? V_out + (size_t)i0 * t : V;
-    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, s);
+    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, st0);
     if (rc) break;
-    rc = hmv_yw_solve_f64(R, c, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, s);
+    const int64_t c0 = (split && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
+    if (c1 > 0) {
+      (void)hipEventRecord(ev_fork, st0);
+      (void)hipStreamWaitEvent(st1, ev_fork, 0);
+      rc = hmv_yw_solve_f64(R + (size_t)c0 * (p + 1) * t, c1, m, p, ws + (size_t)c0 * ws_item,
+                            ar_c + (size_t)c0 * t * p, V_c + (size_t)c0 * t, nullptr, info_yw + i0 + c0, st1);
+      (void)hipEventRecord(ev_join, st1);
+      if (rc) break;
+    }
+    rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, st0);
+    if (c1 > 0) (void)hipStreamWaitEvent(st0, ev_join, 0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
-    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), S(s));
-    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, arx, s);
-    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), S(s));
+    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st0);
+    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, arx, st0);
+    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st0);
     if (rc) break;
-    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, s);
+    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, st0);
   }
-  if (lanes == 2) {
-    // join: the caller's stream continues only after the auxiliary stream has drained
-    (void)hipEventRecord(ev_join, st[1]);
-    (void)hipStreamWaitEvent(st[0], ev_join, 0);
+  if (split) {
     (void)hipEventDestroy(ev_fork);
     (void)hipEventDestroy(ev_join);
   }

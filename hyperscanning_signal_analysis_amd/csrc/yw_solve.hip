@@ -466,8 +466,12 @@ __global__ void __launch_bounds__(256) yw_emit_kernel(YwArgs a) {
   const int p = a.p;
   const YwPtrs q = yw_ptrs<MP>(a, item);
   double* ar = a.ar + (size_t)item * TILE * p;
-  for (int e = threadIdx.x; e < TILE; e += 256)
-    for (int k = 0; k < p; ++k) ar[(size_t)e * p + k] = q.Zt[(size_t)k * TILE + e];
+  // consecutive threads write consecutive addresses (lag fastest); the reads are p runs of 256/p elements
+  const int total = TILE * p;
+  for (int idx = blockIdx.y * 256 + threadIdx.x; idx < total; idx += gridDim.y * 256) {
+    const int e = idx / p, k = idx - e * p;
+    ar[idx] = q.Zt[(size_t)k * TILE + e];
+  }
 }
 
 template <int NT>
@@ -480,7 +484,7 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
     if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(n, p - tb), dim3(256), 0, st, a, tb);
   }
   for (int c = p - 1; c >= 1; --c) hipLaunchKernelGGL(yw_back_kernel<NT>, dim3(n, c), dim3(256), 0, st, a, c);
-  hipLaunchKernelGGL(yw_emit_kernel<NT>, dim3(n), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(yw_emit_kernel<NT>, dim3(n, 16), dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 

@@ -159,7 +159,7 @@ class Engine:
     def sliding_chunk(self, n_items: int, m: int, p: int, F: int, lanes: int = 1) -> int:
         per_item = int(self.lib.hmv_sliding_workspace_bytes(1, m, p, F))
         cap = max(1, self.max_workspace_bytes // max(per_item * lanes, 1))
-        want = -(-n_items // lanes)            # two lanes: at least two chunks so they can overlap
+        want = n_items
         return max(1, min(want, cap))
 
     def aux_stream(self):
@@ -172,8 +172,8 @@ class Engine:
                       check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = False):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
-        overlap: alternate chunks between the current stream and a second stream (see include/hypermvar.h);
-        measured gain on the north-star workload is small (~2 %), so it is off by default.
+        overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the
+        chip, then runs as two half-batches that interleave on the device (see include/hypermvar.h).
         k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
         have been recorded once) which the library records around the dominant kernel.
         """
@@ -184,11 +184,10 @@ class Engine:
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
-        lanes = 2 if (overlap and n_items >= 8) else 1
-        chunk = self.sliding_chunk(n_items, m, p, F, lanes) if chunk is None else int(chunk)
-        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F)) * lanes
+        chunk = self.sliding_chunk(n_items, m, p, F) if chunk is None else int(chunk)
+        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F))
         ws = self._workspace(nbytes)
-        aux = self.aux_stream().cuda_stream if lanes == 2 else 0
+        aux = self.aux_stream().cuda_stream if overlap else 0
         if out is None:
             out = self.empty(n_items, m, m, F)
         ar = self.empty(n_items, mp, mp, p) if return_ar else None

@@ -92,10 +92,10 @@ int hmv_spectra_f64(const double* H, const double* V, double* S, int64_t n_items
  * ev_k3_start / ev_k3_stop (optional hipEvent_t, NULL to skip) are recorded on `stream` right before
  * and after the LAST chunk's K3 launch, so a caller can time the dominant kernel inside its own timed
  * region without an extra synchronisation.
- * aux_stream (optional second hipStream_t, NULL to disable): chunks alternate between `stream` and
- * `aux_stream` (fork/join with events, so the call still behaves as one operation on `stream`); the
- * HBM-bound K4 and the low-occupancy phases of K2 of one chunk then overlap the VALU-bound K3 of the other.
- * With an aux stream the workspace must hold TWO chunks: 2 * hmv_sliding_workspace_bytes(chunk, ...). */
+ * aux_stream (optional second hipStream_t, NULL to disable): the Yule-Walker stage K2 -- ~25 launches of a
+ * few workgroups per window that cannot fill the chip -- runs as two half-batches, one per stream (fork
+ * after K1, join before K3), so their launches interleave on the device; the call still behaves as one
+ * operation on `stream`. */
 int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F);
 int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
