@@ -169,7 +169,7 @@ class Engine:
 
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
-                      check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = False):
+                      check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
         overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the

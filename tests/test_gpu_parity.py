@@ -245,7 +245,8 @@ def test_northstar_full_size_properties():
 
 
 def test_two_stream_overlap_is_bit_identical():
-    """Chunks alternating between two HIP streams (fork/join inside the fused C call) give the same bits."""
+    """K2 split into two half-batches on two HIP streams (fork/join inside the fused C call), and chunking of
+    the windows, give the same bits as one stream / one chunk."""
     eng = default_engine()
     x = synthetic_var_dyad(5, T=12_000)
     freqs = northstar_freqs(64)
@@ -254,10 +255,11 @@ def test_two_stream_overlap_is_bit_identical():
     pos, w = window_positions(12_000, 23, 1000)
     rec, st = window_items(1, pos, eng.device)
     a = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=False)
-    b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=6, overlap=True)
+    b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=True)     # 12 + 11 windows
     c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False)
+    d = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=17, overlap=True)     # 9 + 8, then 6 unsplit
     torch.cuda.synchronize()
-    assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
 
 
 def test_multi_dyad_batch_matches_single_dyad_runs():
