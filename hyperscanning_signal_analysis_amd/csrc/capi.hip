@@ -84,7 +84,7 @@ int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw
   if ((P == nullptr) != (rowsum == nullptr)) return fail(-5, "hmv_tf_f64: P and rowsum go together");
   if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_f64: pivot_tau must be in (0, 1]");
   hmv::TfArgs a;
-  a.ar = ar; a.arx = ws; a.tw = tw; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
+  a.ar = ar; a.arx = ws; a.tw = tw; a.Zin = nullptr; a.detph = nullptr; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
   a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   a.stamps = nullptr;
 #ifdef HMV_STAMP
@@ -118,6 +118,41 @@ int hmv_spectra_f64(const double* H, const double* V, double* Sout, int64_t n_it
   hmv::SpecArgs a;
   a.H = H; a.V = V; a.S = Sout; a.n_items = n_items; a.F = F;
   return hmv::launch_spectra(a, mp, S(stream));
+}
+
+int hmv_pack_c128(const double* in, double* out, int64_t n_items, int F, int m, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_pack_c128: channel count must be in 1..64");
+  if (!in || !out || n_items < 0 || F < 0) return fail(-4, "hmv_pack_c128: null pointer");
+  return hmv::launch_pack_c128(in, out, n_items, F, m, mp, S(stream));
+}
+
+int hmv_cinv_c128(const double* Z, int64_t n_items, int m, int F, double* Zinv, double* detph, int32_t* info,
+                  double pivot_tau, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_cinv_c128: channel count must be in 1..64");
+  if (!Z || !Zinv || !info || n_items < 0 || F < 0) return fail(-4, "hmv_cinv_c128: null pointer");
+  if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_cinv_c128: pivot_tau must be in (0, 1]");
+  hmv::TfArgs a;
+  a.ar = nullptr; a.arx = nullptr; a.tw = nullptr; a.Zin = Z; a.detph = detph; a.P = nullptr; a.rowsum = nullptr;
+  a.H = Zinv; a.A = nullptr; a.info = info; a.n_items = n_items; a.F = F; a.p = 0; a.m = m; a.tau = pivot_tau;
+  a.stamps = nullptr;
+  return hmv::launch_cinv(a, mp, S(stream));
+}
+
+int hmv_partial_coherence_c128(const double* Sinv, const double* detph, double* kappa, int64_t n_items, int m, int F,
+                               void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_partial_coherence_c128: channel count must be in 1..64");
+  if (!Sinv || !detph || !kappa || n_items < 0 || F < 0) return fail(-4, "hmv_partial_coherence_c128: null pointer");
+  return hmv::launch_pcoh(Sinv, detph, kappa, n_items, F, m, mp, S(stream));
+}
+
+int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, int m, int F, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_gpdc_f64: channel count must be in 1..64");
+  if (!A || !V || !G || n_items < 0 || F < 0) return fail(-4, "hmv_gpdc_f64: null pointer");
+  return hmv::launch_gpdc(A, V, G, n_items, F, m, mp, S(stream));
 }
 
 // ---- fused sliding-window path ----------------------------------------------------------------------

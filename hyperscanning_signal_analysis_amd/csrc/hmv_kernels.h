@@ -37,6 +37,8 @@ struct TfArgs {
   const double* ar;         // [n_items][MP][MP][p]  (reference layout; read by the packing kernel only)
   const double* arx;        // scratch, tf_workspace_doubles(): the same coefficients in K3's register order
   const double* tw;         // [F][p][2]
+  const double* Zin;        // general inverse only: complex [n_items][F][MP][MP] (ar / arx / tw unused)
+  double* detph;            // general inverse only, optional: [n_items*F][2] det / |det| incl. interchange sign
   double* P;                // optional [n_items][F][MP][MP]
   double* rowsum;           // required with P: [n_items][F][MP]
   double* H;                // optional complex [n_items][F][MP][MP]
@@ -49,6 +51,7 @@ struct TfArgs {
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
 int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);
+int launch_cinv(const TfArgs& a, int m_pad, hipStream_t st);
 long long tf_workspace_doubles(long long n_items, int m_pad, int p);
 
 // ---- K4 ffDTF normalisation + layout transposes -------------------------------------------------
@@ -75,5 +78,10 @@ struct SpecArgs {
   int F;
 };
 int launch_spectra(const SpecArgs& a, int m_pad, hipStream_t st);
+
+// ---- measures on top of K3 / K5 (connect.hip) -----------------------------------------------------------
+int launch_pack_c128(const double* in, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
+int launch_pcoh(const double* Sinv, const double* detph, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
+int launch_gpdc(const double* A, const double* V, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
 
 }  // namespace hmv

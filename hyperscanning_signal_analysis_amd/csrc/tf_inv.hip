@@ -79,7 +79,10 @@ struct TfLds {
   static constexpr int TOTAL = PBUF + NRING * NBUF + SROW + SWAPB + RSUM;
 };
 
-template <int NT>
+// GEN = false: A(f) from the AR coefficients (the hot path).  GEN = true: the same inversion of arbitrary
+// complex matrices Zin[item][f][MP][MP] (partial coherence of a spectral matrix, mtmvar.py:287-338), which
+// also returns the unit-modulus phase of the determinant (product of the pivots, sign of the interchanges).
+template <int NT, bool GEN>
 __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfArgs a) {
   constexpr int MP = 16 * NT, NG = NT, NSTEP = MP / 4;
   using L = TfLds<NT>;
@@ -88,6 +91,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   __shared__ int s_orig[MP];
   __shared__ __attribute__((aligned(16))) int s_swp[NR][4];
   __shared__ int s_info;
+  __shared__ double s_det[2];                   // GEN: running unit-modulus product of the pivots
 
   const int l = lane_id();
   const int wv = uni(threadIdx.x >> 6);         // hardware wave index inside the workgroup
@@ -118,7 +122,17 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
 #endif
 
   // ---------------------------------------------------------------- A(f), this wave's 16 columns
-  {
+  if constexpr (GEN) {
+    const double2* Zi = reinterpret_cast<const double2*>(a.Zin) + (size_t)gw * MP * MP + (size_t)rowl * MP + colw;
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+      for (int Jl = 0; Jl < 4; ++Jl) {
+        const double2 v = Zi[(size_t)(16 * Ig) * MP + 4 * NT * Jl];
+        re[Ig][Jl] = v.x;
+        im[Ig][Jl] = v.y;
+      }
+  } else {
     // Coefficients in the packed layout written by ar_pack_kernel: for wave w, register (Ig, Jl) and lag pair
     // h the 64 lanes' (a[2h], a[2h+1]) are 1 KB contiguous, so every load instruction is one fully coalesced
     // 16-B/lane read (the reference (m, m, p) layout costs 64 partial cache lines per instruction).
@@ -184,7 +198,11 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   }
   if (w == 0) {
     if (l < MP) s_orig[l] = l;
-    if (l == 0) s_info = 0;
+    if (l == 0) {
+      s_info = 0;
+      s_det[0] = 1.0;
+      s_det[1] = 0.0;
+    }
   }
   const double tau = a.tau;
   HMV_T(0);
@@ -207,6 +225,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
     }
     int rs[4], bad = 0;      // pivot rows of the four columns, first zero pivot (+1): wave-uniform
+    double dpr = 1.0, dpi = 0.0;   // GEN: unit-modulus product of this panel's pivots (wave-uniform)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * t + jj;
@@ -255,6 +274,16 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         }
       }
       rs[jj] = rstar;
+      if constexpr (GEN) {       // det *= pivot / |pivot|, negated by an interchange
+        double rsq = __builtin_amdgcn_rsq(dd);
+        rsq = rsq * __builtin_fma(-0.5 * dd * rsq, rsq, 1.5);
+        rsq = rsq * __builtin_fma(-0.5 * dd * rsq, rsq, 1.5);
+        const double sg = (rstar != col) ? -rsq : rsq;
+        const double ur = pr * sg, ui = pi * sg;
+        const double nr_ = __builtin_fma(dpr, ur, -(dpi * ui)), ni_ = __builtin_fma(dpr, ui, dpi * ur);
+        dpr = nr_;
+        dpi = ni_;
+      }
       if (l == rstar) {
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
@@ -301,6 +330,11 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     if (l == 0) {
       *reinterpret_cast<int4*>(&s_swp[t % NR][0]) = make_int4(rs[0], rs[1], rs[2], rs[3]);
       if (bad != 0 && s_info == 0) s_info = bad;
+      if constexpr (GEN) {
+        const double qr = s_det[0], qi = s_det[1];
+        s_det[0] = __builtin_fma(qr, dpr, -(qi * dpi));
+        s_det[1] = __builtin_fma(qr, dpi, qi * dpr);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -460,7 +494,15 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
 #pragma unroll
   for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[4 * (Jl * NT + w) + jo];
-  if (w == 0 && lo == 0) a.info[gw] = s_info;
+  if (w == 0 && lo == 0) {
+    a.info[gw] = s_info;
+    if constexpr (GEN) {
+      if (a.detph) {
+        a.detph[2 * gw] = s_det[0];
+        a.detph[2 * gw + 1] = s_det[1];
+      }
+    }
+  }
 
   if (a.H) {
     double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)rowo * MP;
@@ -562,20 +604,35 @@ int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st) {
   switch (m_pad) {
     case 16:
       hipLaunchKernelGGL(ar_pack_kernel<1>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
-      hipLaunchKernelGGL(tf_inv_kernel<1>, grid, dim3(64), 0, st, a);
+      hipLaunchKernelGGL((tf_inv_kernel<1, false>), grid, dim3(64), 0, st, a);
       break;
     case 32:
       hipLaunchKernelGGL(ar_pack_kernel<2>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
-      hipLaunchKernelGGL(tf_inv_kernel<2>, grid, dim3(128), 0, st, a);
+      hipLaunchKernelGGL((tf_inv_kernel<2, false>), grid, dim3(128), 0, st, a);
       break;
     case 48:
       hipLaunchKernelGGL(ar_pack_kernel<3>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
-      hipLaunchKernelGGL(tf_inv_kernel<3>, grid, dim3(192), 0, st, a);
+      hipLaunchKernelGGL((tf_inv_kernel<3, false>), grid, dim3(192), 0, st, a);
       break;
     case 64:
       hipLaunchKernelGGL(ar_pack_kernel<4>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
-      hipLaunchKernelGGL(tf_inv_kernel<4>, grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), 0, st, a);
       break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+// general complex inverse of a.Zin (kernel layout), a.H = inverse, a.detph = phase of the determinants
+int launch_cinv(const TfArgs& a, int m_pad, hipStream_t st) {
+  const long long n = a.n_items * (long long)a.F;
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)n);
+  switch (m_pad) {
+    case 16: hipLaunchKernelGGL((tf_inv_kernel<1, true>), grid, dim3(64), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((tf_inv_kernel<2, true>), grid, dim3(128), 0, st, a); break;
+    case 48: hipLaunchKernelGGL((tf_inv_kernel<3, true>), grid, dim3(192), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((tf_inv_kernel<4, true>), grid, dim3(256), 0, st, a); break;
     default: return -1;
   }
   return (int)hipGetLastError();

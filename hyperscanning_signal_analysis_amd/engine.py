@@ -155,6 +155,51 @@ class Engine:
         _lib.check(rc, "hmv_spectra_f64")
         return S
 
+    # ------------------------------------------------------------------ measures on top of K3 / K5
+    def pack_complex(self, Z: torch.Tensor):
+        """complex128 (items, m, m, F) -> kernel layout (items, F, MP, MP, 2), identity on the padding."""
+        n_items, m, _, F = Z.shape
+        mp = self.pad(m)
+        zin = torch.view_as_real(Z.contiguous())
+        out = self.empty(n_items, F, mp, mp, 2)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_pack_c128(zin.data_ptr(), out.data_ptr(), n_items, F, m, self.stream())
+        _lib.check(rc, "hmv_pack_c128")
+        return out
+
+    def complex_inverse(self, Z: torch.Tensor, m: int):
+        """Z (items, F, MP, MP, 2) -> (inverse, det/|det| (items*F, 2), info)."""
+        n_items, F, mp, _, _ = Z.shape
+        Zi = self.empty(n_items, F, mp, mp, 2)
+        detph = self.empty(n_items * F, 2)
+        info = self.empty(n_items * F, dtype=torch.int32)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_cinv_c128(Z.data_ptr(), n_items, m, F, Zi.data_ptr(), detph.data_ptr(), info.data_ptr(),
+                                        self.pivot_tau, self.stream())
+        _lib.check(rc, "hmv_cinv_c128")
+        return Zi, detph, info
+
+    def partial_coherence(self, S: torch.Tensor, m: int):
+        """S spectral matrices (items, F, MP, MP, 2) in kernel layout -> kappa complex128 (items, m, m, F)."""
+        n_items, F, mp, _, _ = S.shape
+        Si, detph, info = self.complex_inverse(S, m)
+        kap = self.empty(n_items, F, mp, mp, 2)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_partial_coherence_c128(Si.data_ptr(), detph.data_ptr(), kap.data_ptr(), n_items, m, F,
+                                                     self.stream())
+        _lib.check(rc, "hmv_partial_coherence_c128")
+        return self.to_mmf_complex(kap, m), info
+
+    def gpdc(self, A: torch.Tensor, V: torch.Tensor, m: int):
+        """A (items, F, MP, MP, 2) from `transfer(want_A=True)`, V (items, MP, MP) -> GPDC (items, m, m, F)."""
+        n_items, F, mp, _, _ = A.shape
+        G = self.empty(n_items, F, mp, mp)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_gpdc_f64(A.data_ptr(), V.data_ptr(), G.data_ptr(), n_items, m, F, self.stream())
+        _lib.check(rc, "hmv_gpdc_f64")
+        out, _ = self.normalise(G, None, m, normalise=False)
+        return out
+
     # ------------------------------------------------------------------ fused sliding-window path
     def sliding_chunk(self, n_items: int, m: int, p: int, F: int, lanes: int = 1) -> int:
         per_item = int(self.lib.hmv_sliding_workspace_bytes(1, m, p, F))

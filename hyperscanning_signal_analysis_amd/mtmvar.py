@@ -123,7 +123,8 @@ def mvar_transfer_function(ar_coeffs, freqs, fs):
 
 
 def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
-    """One fit, several products: any of 'ar', 'V', 'H', 'A', 'dtf', 'ffdtf', 'spectra' as a dict.
+    """One fit, several products: any of 'ar', 'V', 'H', 'A', 'dtf', 'ffdtf', 'spectra', 'pcoh', 'ddtf', 'gpdc'
+    as a dict.
 
     Not in the reference (which refits for every product, mtmvar.py:165-284); this is what the pipeline
     mirror uses so that ffDTF and spectra share the lag covariances, the solve and the inverses.
@@ -132,9 +133,10 @@ def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
     p = int(model_order)
     ar, V, _, m, _ = _fit(signals, p, eng)
     tw = eng.twiddles(freqs, fs, p)
-    need_H = any(k in want for k in ("H", "spectra"))
-    need_P = any(k in want for k in ("dtf", "ffdtf"))
-    t = eng.transfer(ar, m, tw, want_P=need_P, want_H=need_H, want_A="A" in want)
+    need_S = any(k in want for k in ("spectra", "pcoh", "ddtf"))
+    need_H = ("H" in want) or need_S
+    need_P = any(k in want for k in ("dtf", "ffdtf", "ddtf"))
+    t = eng.transfer(ar, m, tw, want_P=need_P, want_H=need_H, want_A=any(k in want for k in ("A", "gpdc")))
     eng.raise_on_info(t["info"], "transfer")
     res = {}
     if "ar" in want:
@@ -147,11 +149,24 @@ def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
         res["A"] = eng.to_mmf_complex(t["A"], m)[0].cpu().numpy()
     if "dtf" in want:
         res["dtf"] = eng.normalise(t["P"], t["rowsum"], m, normalise=False)[0][0].cpu().numpy()
+    ff = None
+    if "ffdtf" in want or "ddtf" in want:
+        ff = eng.normalise(t["P"], t["rowsum"], m, normalise=True)[0]
     if "ffdtf" in want:
-        res["ffdtf"] = eng.normalise(t["P"], t["rowsum"], m, normalise=True)[0][0].cpu().numpy()
-    if "spectra" in want:
+        res["ffdtf"] = ff[0].cpu().numpy()
+    if need_S:
         S = eng.spectra(t["H"], V, m)
-        res["spectra"] = eng.to_mmf_complex(S, m)[0].cpu().numpy()
+        if "spectra" in want:
+            res["spectra"] = eng.to_mmf_complex(S, m)[0].cpu().numpy()
+        if "pcoh" in want or "ddtf" in want:
+            kappa, info = eng.partial_coherence(S, m)
+            eng.raise_on_info(info, "partial_coherence")
+            if "pcoh" in want:
+                res["pcoh"] = kappa[0].cpu().numpy()
+            if "ddtf" in want:
+                res["ddtf"] = (ff[0] * kappa[0].abs()).cpu().numpy()
+    if "gpdc" in want:
+        res["gpdc"] = eng.gpdc(t["A"], V, m)[0].cpu().numpy()
     return res
 
 
@@ -171,6 +186,37 @@ def full_freq_dtf(signals, freqs, fs, max_model_order=20, optimal_model_order=No
     """ffDTF_ij(f) = |H_ij(f)|^2 / sum_f sum_k |H_ik(f)|^2 (mtmvar.py:237-284)."""
     p = _order(signals, max_model_order, optimal_model_order, crit_type, False, None, "dtf")
     return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("ffdtf",))["ffdtf"]
+
+
+def partial_coherence(spectra):
+    """kappa_ij = M_ij / sqrt(M_ii M_jj) with M the minors of the spectral matrix (mtmvar.py:287-338), computed
+    from the inverse: M_ij = (-1)^(i+j) det(S) (S^-1)_ji.  (N_chan, N_chan, N_f) complex128 in and out."""
+    import torch
+    eng = default_engine()
+    S = np.ascontiguousarray(np.asarray(spectra, dtype=np.complex128))
+    n_chan = S.shape[0]
+    if S.ndim != 3 or S.shape[1] != n_chan:
+        raise ValueError("spectra must have shape (N_chan, N_chan, N_f)")
+    eng.pad(n_chan)
+    Sk = eng.pack_complex(torch.from_numpy(S)[None].to(eng.device))
+    kappa, info = eng.partial_coherence(Sk, n_chan)
+    eng.raise_on_info(info, "partial_coherence")
+    return kappa[0].cpu().numpy()
+
+
+def direct_dtf(signals, freqs, fs, max_model_order=20, optimal_model_order=None, crit_type='AIC'):
+    """dDTF = ffDTF * |partial coherence| (mtmvar.py:341-385); one fit instead of the reference's two."""
+    p = _order(signals, max_model_order, optimal_model_order, crit_type, True, None, "spectra")
+    _order(signals, max_model_order, p if optimal_model_order is None else optimal_model_order, crit_type, False,
+           None, "dtf")
+    return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("ddtf",))["ddtf"]
+
+
+def gen_partial_directed_coherence(signals, freqs, fs, max_model_order=20, optimal_model_order=None,
+                                   crit_type='AIC'):
+    """GPDC_ij(f) = |A_ij|/sigma_i / sqrt(sum_k |A_kj|^2/sigma_k^2) (mtmvar.py:388-468)."""
+    p = _order(signals, max_model_order, optimal_model_order, crit_type, False, None, "spectra")
+    return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("gpdc",))["gpdc"]
 
 
 def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):

@@ -84,6 +84,23 @@ int hmv_transpose_c128(const double* in, double* out, int64_t n_items, int F, in
 /* K5.  S[item][f] = H V H^T, plain transpose (src/mtmvar.py:199).  H, S complex128 [item][f][MP][MP]. */
 int hmv_spectra_f64(const double* H, const double* V, double* S, int64_t n_items, int m, int F, void* stream);
 
+/* ---- measures on top of the per-frequency matrices ----------------------------
+ * hmv_pack_c128: complex (items, m, m, F) -- the reference's array layout -- to the kernel layout
+ *   [item][f][MP][MP] with the identity on the padding (inverse of hmv_transpose_c128).
+ * hmv_cinv_c128: Zinv[item][f] = inv(Z[item][f]) by K3's blocked Gauss-Jordan (same pivoting rule);
+ *   detph (optional): [item*F + f][2] = det / |det| (product of the pivots, sign of the interchanges).
+ * hmv_partial_coherence_c128: kappa from Sinv = inverse spectral matrix and its detph; replaces
+ *   partial_coherence (src/mtmvar.py:287-338: minors by np.linalg.det) through M_ij = (-1)^(i+j) det (S^-1)_ji;
+ *   kappa: complex [item][f][MP][MP] (hmv_transpose_c128 brings it to (m, m, F)).
+ * hmv_gpdc_f64: generalised partial directed coherence from A(f) (hmv_tf_f64's A output) and V
+ *   (src/mtmvar.py:388-468); G: real [item][f][MP][MP] (hmv_ffdtf_norm_f64 with normalise = 0 transposes it). */
+int hmv_pack_c128(const double* in, double* out, int64_t n_items, int F, int m, void* stream);
+int hmv_cinv_c128(const double* Z, int64_t n_items, int m, int F, double* Zinv, double* detph, int32_t* info,
+                  double pivot_tau, void* stream);
+int hmv_partial_coherence_c128(const double* Sinv, const double* detph, double* kappa, int64_t n_items, int m,
+                               int F, void* stream);
+int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, int m, int F, void* stream);
+
 /* Fused sliding-window path K1 -> K2 -> K3 -> K4 over all items, processed `chunk` items at a time so the
  * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].

@@ -170,6 +170,49 @@ def multivariate_spectra(signals, freqs, fs, optimal_model_order):
 
 
 # --------------------------------------------------------------------------- a7
+def partial_coherence(spectra):
+    """kappa_ij = M_ij / sqrt(M_ii M_jj), M_ij = det(S without row i and column j) (no cofactor sign), 1 on the
+    diagonal, 0 where the denominator is zero (reference: src/mtmvar.py:287-338, minors :302-322, ratio :324-336).
+    Restated with the same minors-by-determinant arithmetic (vectorised over frequency)."""
+    S = np.asarray(spectra, dtype=np.complex128)
+    n, _, F = S.shape
+    minors = np.ones((n, n, F), dtype=np.complex128)
+    if n > 1:
+        St = np.ascontiguousarray(S.transpose(2, 0, 1))
+        for i in range(n):
+            rows = [r for r in range(n) if r != i]
+            for j in range(n):
+                cols = [c for c in range(n) if c != j]
+                minors[i, j] = np.linalg.det(St[:, rows][:, :, cols])
+    kappa = np.zeros((n, n, F), dtype=np.complex128)
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                kappa[i, j] = 1.0
+            else:
+                den = np.sqrt(minors[i, i] * minors[j, j])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    kappa[i, j] = np.where(den != 0, minors[i, j] / den, 0)
+    return kappa
+
+
+def direct_dtf(signals, freqs, fs, optimal_model_order):
+    """dDTF = ffDTF * |kappa| (src/mtmvar.py:341-385, product at :383)."""
+    S = multivariate_spectra(signals, freqs, fs, optimal_model_order)
+    return full_freq_dtf(signals, freqs, fs, optimal_model_order) * np.abs(partial_coherence(S))
+
+
+def gen_partial_directed_coherence(signals, freqs, fs, optimal_model_order):
+    """GPDC_ij = (|A_ij| / sigma_i) / sqrt(sum_k |A_kj|^2 / sigma_k^2) (src/mtmvar.py:388-468, loops :452-466)."""
+    ar, V = ar_coeff(signals, optimal_model_order)
+    _, A = mvar_transfer_function(ar, freqs, fs)
+    s2 = np.diag(V)
+    num = np.abs(A) / np.sqrt(s2)[:, None, None]
+    den = np.sqrt(np.sum(np.abs(A) ** 2 / s2[:, None, None], axis=0))          # (j, f)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(den[None] != 0, num / den[None], 0.0)
+
+
 def mvar_criterion(data, max_model_order, crit_type="AIC"):
     """AIC / HQ / SC curves (mtmvar.py:551-601, quirk Q7).  Returns (crit, range, p_opt)."""
     m, n = data.shape

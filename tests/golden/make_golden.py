@@ -18,6 +18,9 @@ Fixture list:
   g5_multitrial.npz multi-trial input (5, 400, 4): r_left, r_right, r, ar, V.
   g6_errors.npz     inputs that make the reference raise (singular window), plus window-geometry
                     error cases (recorded as message strings).
+  g7_connectivity.npz  partial_coherence / direct_dtf / gen_partial_directed_coherence on
+                    the G1 signal (m=3, p=4), a 4x480 block (p=5), a 7-channel VAR(3), and partial_coherence of
+                    an arbitrary complex 5x5x6 array.  `python tests/golden/make_golden.py g7` writes only this.
 """
 import io
 import os
@@ -68,7 +71,30 @@ def small_var(seed, m, p, n, scale=0.4):
     return np.ascontiguousarray(x[burn:].T)
 
 
+def make_g7():
+    g = {}
+    cases = {"a": (small_var(11, 3, 4, 4000), 128.0, np.arange(1, 41, 2.0), 4),
+             "b": (small_var(44, 4, 2, 480), 8.0, np.linspace(0.0, 4.0, 30, endpoint=False)[1:], 5),
+             "c": (small_var(77, 7, 3, 800), 100.0, np.linspace(1.0, 45.0, 9), 3)}
+    for tag, (x, fs, freqs, p) in cases.items():
+        S = quiet(ref.multivariate_spectra, x, freqs, fs, optimal_model_order=p)
+        g[f"x_{tag}"], g[f"fs_{tag}"], g[f"freqs_{tag}"], g[f"p_{tag}"] = x, fs, freqs, p
+        g[f"spectra_{tag}"] = S
+        g[f"pcoh_{tag}"] = ref.partial_coherence(S)
+        g[f"ddtf_{tag}"] = quiet(ref.direct_dtf, x, freqs, fs, optimal_model_order=p)
+        g[f"gpdc_{tag}"] = quiet(ref.gen_partial_directed_coherence, x, freqs, fs, optimal_model_order=p)
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal((5, 5, 6)) + 1j * rng.standard_normal((5, 5, 6))
+    g["Z"], g["pcoh_Z"] = Z, ref.partial_coherence(Z)
+    g["pcoh_1x1"] = ref.partial_coherence(np.full((1, 1, 3), 2.0 + 1.0j))
+    np.savez_compressed(os.path.join(HERE, "g7_connectivity.npz"), **g)
+    print("g7_connectivity.npz written")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        make_g7()
+        return
     out = {}
     # ------------------------------------------------------------------ G1
     x = small_var(11, 3, 4, 4000)
@@ -180,6 +206,7 @@ def main():
             msgs.append(str(e))
     g6["window_errors"] = np.array(msgs)
     np.savez_compressed(os.path.join(HERE, "g6_errors.npz"), xs=xs, xz=xz, **g6)
+    make_g7()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

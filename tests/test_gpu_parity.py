@@ -136,6 +136,41 @@ def test_g6_error_behaviour(golden):
         M.ar_coeff(np.zeros((70, 500)), 2)                                  # > 64 channels: refused loudly
 
 
+def test_g7_partial_coherence_ddtf_gpdc(golden, capsys):
+    """the three measures of src/mtmvar.py:287-468 against the reference's own outputs."""
+    g = golden("g7_connectivity.npz")
+    for tag in "abc":
+        x, fs, freqs, p = g[f"x_{tag}"], float(g[f"fs_{tag}"]), g[f"freqs_{tag}"], int(g[f"p_{tag}"])
+        kap = M.partial_coherence(g[f"spectra_{tag}"])
+        assert kap.dtype == np.complex128
+        assert_parity(kap, g[f"pcoh_{tag}"])
+        assert_parity(M.direct_dtf(x, freqs, fs, optimal_model_order=p), g[f"ddtf_{tag}"])
+        assert_parity(M.gen_partial_directed_coherence(x, freqs, fs, optimal_model_order=p), g[f"gpdc_{tag}"])
+    assert "Using provided model order" in capsys.readouterr().out
+    assert_parity(M.partial_coherence(g["Z"]), g["pcoh_Z"])              # arbitrary (non-MVAR) complex matrices
+    assert np.array_equal(M.partial_coherence(np.full((1, 1, 3), 2.0 + 1.0j)), g["pcoh_1x1"])
+
+
+@pytest.mark.parametrize("m,p,n,F", [(5, 2, 400, 6), (19, 3, 900, 5), (33, 2, 1200, 3)])
+def test_connectivity_measures_vs_oracle(m, p, n, F):
+    rng = np.random.default_rng(7 * m + p)
+    x = rng.standard_normal((m, n))
+    x[:, 1:] += 0.5 * x[:, :-1]
+    x[1:] += 0.3 * x[:-1]
+    freqs = np.linspace(2.0, 40.0, F)
+    res = M.mvar_analysis(x, freqs, 100.0, p, want=("pcoh", "ddtf", "gpdc", "spectra"))
+    assert_parity(res["gpdc"], O.gen_partial_directed_coherence(x, freqs, 100.0, p), 1e-8)
+    assert np.abs((res["gpdc"] ** 2).sum(axis=0) - 1.0).max() < 1e-12           # columns of GPDC^2 sum to one
+    if m <= 19:        # minors by determinant: O(m^5 F) on the host
+        kap = O.partial_coherence(O.multivariate_spectra(x, freqs, 100.0, p))
+        assert_parity(np.abs(res["pcoh"]), np.abs(kap), 1e-7)
+        assert_parity(res["ddtf"], O.direct_dtf(x, freqs, 100.0, p), 1e-7)
+    else:              # size-independent properties: unit diagonal, |kappa| symmetric for a complex-symmetric S
+        k = res["pcoh"]
+        assert np.allclose(k[np.arange(m), np.arange(m)], 1.0)
+        assert np.abs(np.abs(k) - np.abs(k).transpose(1, 0, 2)).max() < 1e-8
+
+
 # ----------------------------------------------------------------------------- oracle on seeded inputs
 @pytest.mark.parametrize("m,p,n,F", [(1, 1, 50, 3), (2, 3, 120, 5), (7, 2, 300, 9), (16, 5, 400, 17),
                                      (17, 4, 500, 8), (19, 6, 700, 33), (32, 3, 600, 16), (33, 2, 500, 7),

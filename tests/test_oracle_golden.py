@@ -103,3 +103,15 @@ def test_g6_errors(golden):
         with pytest.raises(ValueError) as e:
             O.window_positions(T, nw, ws)
         assert str(e.value) == str(msg)
+
+
+def test_g7_connectivity_measures(golden):
+    """partial_coherence / direct_dtf / gen_partial_directed_coherence (src/mtmvar.py:287-468)."""
+    g = golden("g7_connectivity.npz")
+    for tag in "abc":
+        x, fs, freqs, p = g[f"x_{tag}"], float(g[f"fs_{tag}"]), g[f"freqs_{tag}"], int(g[f"p_{tag}"])
+        assert rel(O.partial_coherence(g[f"spectra_{tag}"]), g[f"pcoh_{tag}"]) < 1e-12
+        assert rel(O.direct_dtf(x, freqs, fs, p), g[f"ddtf_{tag}"]) < 1e-10
+        assert rel(O.gen_partial_directed_coherence(x, freqs, fs, p), g[f"gpdc_{tag}"]) < 1e-12
+    assert rel(O.partial_coherence(g["Z"]), g["pcoh_Z"]) < 1e-13
+    assert np.array_equal(O.partial_coherence(np.full((1, 1, 3), 2.0 + 1.0j)), g["pcoh_1x1"])
