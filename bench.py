@@ -76,17 +76,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--minutes", type=float, default=10.0, help="recording length per dyad (default 10)")
     ap.add_argument("--single-stream", action="store_true", help="do not split K2 over two HIP streams")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code path "
+                         "with several ranks on ONE GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = (args.backend == "gloo")                 # every rank on GPU 0, host-side collectives
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     ns = NORTHSTAR
     m, fs, w, p, F = ns["m"], ns["fs"], ns["window"], ns["p"], ns["F"]
@@ -116,7 +123,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
 
     for _ in range(args.warmup):
         step()
@@ -128,13 +138,13 @@ def main():
         step((ev[k][0].cuda_event, ev[k][1].cuda_event))
     if world > 1:                                                       # the single gather at the end
         bands = hdist.band_integrate(out, freqs)
-        gathered = hdist.gather_to_root(bands, dst=0)
+        gathered = hdist.gather_to_root(bands.cpu() if rehearsal else bands, dst=0)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
