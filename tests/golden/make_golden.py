@@ -21,6 +21,9 @@ Fixture list:
   g7_connectivity.npz  partial_coherence / direct_dtf / gen_partial_directed_coherence on
                     the G1 signal (m=3, p=4), a 4x480 block (p=5), a 7-channel VAR(3), and partial_coherence of
                     an arbitrary complex 5x5x6 array.  `python tests/golden/make_golden.py g7` writes only this.
+  g8_faa_chain.npz  the pipeline's scalar DSP chain on seeded 19 x 10240 noise @128 Hz + a 4 Hz IBI series:
+                    alpha band-pass, FAA (amp and power), downsampling to 8 Hz, crop, z-scored 4 x 480 block and
+                    the reference's _compute_ffDTF on it.  `python tests/golden/make_golden.py g8`.
 """
 import io
 import os
@@ -91,9 +94,44 @@ def make_g7():
     print("g7_connectivity.npz written")
 
 
+def make_g8():
+    P = ref_pipe.EEG_IBI_FFDTF_Pipeline
+    pipe = P.__new__(P)                 # skip the folder scan of __init__; set what the helpers read
+    pipe.left_chan, pipe.right_chan = "F3", "F4"
+    pipe.fs_ds, pipe.freq_min, pipe.freq_step = 8.0, 1.0, 0.1
+    pipe.freq_max = (pipe.fs_ds / 2) - pipe.freq_step
+    pipe.plot_global_enabled = pipe.save_global_enabled = False
+    pipe.plot_windowed_enabled = pipe.save_windowed_enabled = False
+    from g8_inputs import FS_EEG, NAMES, g8_inputs
+    inp = g8_inputs()
+    g, rows = {}, []
+    for role in ("ch", "cg"):
+        eeg = inp[f"eeg_{role}"]
+        filt = quiet(pipe._alpha_bandpass_filter, eeg, FS_EEG)
+        faa = quiet(pipe._compute_asymmetry, filt, NAMES, metric="amp")
+        faa_pow = quiet(pipe._compute_asymmetry, filt, NAMES, metric="power")
+        faa_ds = quiet(pipe._downsample_signal, faa, FS_EEG, 8.0)
+        faa_c = quiet(pipe._crop_signal, faa_ds, 8.0, drop_front_sec=10, keep_duration_sec=60)
+        g.update({f"filt_{role}": filt[[2, 3]], f"faa_{role}": faa, f"faa_pow_{role}": faa_pow,
+                  f"faa_ds_{role}": faa_ds, f"faa_crop_{role}": faa_c})
+        rows += [faa_c, inp[f"ibi8_{role}"]]
+    block = np.vstack(rows)
+    block = (block - np.mean(block, axis=1, keepdims=True)) / np.std(block, axis=1, keepdims=True)
+    g["block"] = block
+    pipe.ar_p = 5
+    ff, sp, p_opt = quiet(pipe._compute_ffDTF, "W_000", block, ["faa_ch", "ibi_ch", "faa_cg", "ibi_cg"], 8.0,
+                          plot=False, save_plot=False)
+    g["ff_block"], g["sp_block"], g["p_block"] = ff, sp, p_opt
+    np.savez_compressed(os.path.join(HERE, "g8_faa_chain.npz"), **g)
+    print("g8_faa_chain.npz written")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         make_g7()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        make_g8()
         return
     out = {}
     # ------------------------------------------------------------------ G1
@@ -207,6 +245,7 @@ def main():
     g6["window_errors"] = np.array(msgs)
     np.savez_compressed(os.path.join(HERE, "g6_errors.npz"), xs=xs, xz=xz, **g6)
     make_g7()
+    make_g8()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

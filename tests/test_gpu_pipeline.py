@@ -97,3 +97,18 @@ def test_compute_and_plot_mvar_with_injected_loader(capsys):
     assert np.abs(sp - ref).max() <= 1e-8 * np.abs(ref).max()
     ff2, _, _, crit2, rng2, p2 = M.compute_and_plot_mvar("x.nc", optimal_model_order=3, plot=False, loader=loader)
     assert p2 == 3 and crit2.size == 0 and rng2.size == 0 and ff2.shape == (5, 5, 79)
+
+
+def test_compute_ffdtf_on_reference_block(tmp_path, golden):
+    """g8: the reference's own `_compute_ffDTF` outputs on the 4 x 480 block of its preprocessing chain."""
+    from hyperscanning_signal_analysis_amd.eeg_alpha_ibi_ffdtf import EEG_IBI_FFDTF_Pipeline
+    g = golden("g8_faa_chain.npz")
+    root = make_tree(tmp_path / "data")
+    pipe = EEG_IBI_FFDTF_Pipeline(root, tmp_path / "out", ["Peppa"], ar_p=5, plot_global_enabled=False,
+                                  save_global_enabled=False, plot_windowed_enabled=False,
+                                  save_windowed_enabled=False)
+    ff, sp, p_opt = pipe._compute_ffDTF("W_000", g["block"], ["faa_ch", "ibi_ch", "faa_cg", "ibi_cg"], 8.0,
+                                        plot=False, save_plot=False)
+    assert p_opt == int(g["p_block"])
+    assert np.abs(ff - g["ff_block"]).max() <= 1e-9 * np.abs(g["ff_block"]).max()
+    assert np.abs(sp - g["sp_block"]).max() <= 1e-9 * np.abs(g["sp_block"]).max()

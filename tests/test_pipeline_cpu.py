@@ -68,3 +68,36 @@ def test_dsp_helpers(tmp_path):
         p._crop_signal(ds[:400], 8.0, 10, 60)
     wins = p._create_windows(np.zeros((4, 480)), 3, None)
     assert [w.shape for w in wins] == [(4, 160)] * 3
+
+
+def test_faa_chain_matches_reference_outputs(tmp_path, golden):
+    """g8: the reference's own _alpha_bandpass_filter / _compute_asymmetry / _downsample_signal / _crop_signal
+    (src/eeg_alpha_ibi_ffdtf.py:271-448) run on seeded inputs; the mirror's SciPy chain must reproduce them."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from g8_inputs import FS_EEG, NAMES, g8_inputs
+    g, inp = golden("g8_faa_chain.npz"), g8_inputs()
+    make_tree(tmp_path)
+    p = EEG_IBI_FFDTF_Pipeline(tmp_path, tmp_path / "out", ["Peppa"])
+    rows = []
+    for role in ("ch", "cg"):
+        filt = p._alpha_bandpass_filter(inp[f"eeg_{role}"], FS_EEG)
+        assert np.allclose(filt[[2, 3]], g[f"filt_{role}"], rtol=1e-9, atol=1e-12)
+        faa = p._compute_asymmetry(filt, NAMES, metric="amp")
+        assert np.allclose(faa, g[f"faa_{role}"], rtol=1e-8, atol=1e-10)
+        assert np.allclose(p._compute_asymmetry(filt, NAMES, metric="power"), g[f"faa_pow_{role}"], rtol=1e-8, atol=1e-10)
+        ds = p._downsample_signal(faa, FS_EEG, 8.0)
+        assert np.allclose(ds, g[f"faa_ds_{role}"], rtol=1e-8, atol=1e-10)
+        crop = p._crop_signal(ds, 8.0, 10, 60)
+        assert np.allclose(crop, g[f"faa_crop_{role}"], rtol=1e-8, atol=1e-10)
+        rows += [crop, inp[f"ibi8_{role}"]]
+    block = np.vstack(rows)
+    block = (block - np.mean(block, axis=1, keepdims=True)) / np.std(block, axis=1, keepdims=True)
+    assert np.allclose(block, g["block"], rtol=1e-8, atol=1e-9)
+    # the numerical part of _compute_ffDTF on this block is pinned on the oracle (CPU) and on the GPU path
+    from oracle import mvar_oracle as O
+    freqs = p._freqs()
+    assert np.allclose(O.full_freq_dtf(g["block"], freqs, 8.0, 5), g["ff_block"], rtol=1e-9, atol=1e-13)
+    assert np.allclose(O.multivariate_spectra(g["block"], freqs, 8.0, 5), g["sp_block"], rtol=1e-9, atol=1e-12)
+    assert int(g["p_block"]) == 5
