@@ -62,6 +62,15 @@ __device__ __forceinline__ double shfl_f64(double v, int src_lane) {
   return u.d;
 }
 
+template <int PATTERN>
+__device__ __forceinline__ double swizzle_f64(double v) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_ds_swizzle(u.i[0], PATTERN);
+  u.i[1] = __builtin_amdgcn_ds_swizzle(u.i[1], PATTERN);
+  return u.d;
+}
+
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src_lane) {
   union { unsigned long long q; int i[2]; } u;
   u.q = v;

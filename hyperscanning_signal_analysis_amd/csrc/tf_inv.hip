@@ -352,12 +352,14 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     }
   };
   // Rank-4 update t of register block J on the matrix pipe.  B operand: pivot row 4t+k at this lane's
-  // column, held by lane (i = k, b = t & 3, j) in register [t >> 2][J] -> one bpermute inside the 16-lane row.
+  // column, held by lane (i = k, b = t & 3, j) in register [t >> 2][J] -> one swizzle inside the 16-lane row.
   auto update_block = [&](auto tc, auto jc, const double (&nr)[NG], const double (&ni)[NG])
                           __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, J = decltype(jc)::value;
-    const int bsrc = (l & 0x33) | ((t & 3) << 2);
-    const double ur = shfl_f64(re[t >> 2][J], bsrc), ui = shfl_f64(im[t >> 2][J], bsrc);
+    // ds_swizzle (bit mode: lane' = (lane & 0x13) | (b << 2) inside each half wave) costs 2.2 cycles of the
+    // LDS pipe against 6.1 for ds_bpermute and needs no address register (tools/ubench_lds.hip)
+    constexpr int pat = 0x13 | (((t & 3) << 2) << 5);
+    const double ur = swizzle_f64<pat>(re[t >> 2][J]), ui = swizzle_f64<pat>(im[t >> 2][J]);
 #pragma unroll
     for (int Ig = 0; Ig < NG; ++Ig) {
       re[Ig][J] = mfma4(nr[Ig], ur, re[Ig][J]);

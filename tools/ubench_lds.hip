@@ -34,6 +34,8 @@ __global__ void __launch_bounds__(1024) k(int* out, unsigned long long* cyc) {
   if (KIND == 3) { R64(asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr_bc) : "memory");) }
   if (KIND == 4) { R64(asm volatile("ds_read_b64 %0, %1" : "=v"(*(long long*)&v) : "v"(addr_b64) : "memory");) }
   if (KIND == 5) { R64(asm volatile("ds_read_b32 %0, %1" : "=v"(a) : "v"(addr_lin >> 2) : "memory");) }
+  if (KIND == 7) { R64(asm volatile("ds_swizzle_b32 %0, %1 offset:0x93" : "=v"(a) : "v"(l) : "memory");) }   // and 0x13, or 0x4
+  if (KIND == 8) { R64(asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(a) : "v"(((l + 1) & 63) * 4), "v"(l) : "memory");) }
   if (KIND == 6) {   // single-lane write (exec = 1 lane), as the pivot-row publish
     if (l == 5) { R64(asm volatile("ds_write_b128 %1, %0" : : "v"(v), "v"(addr_lin) : "memory");) }
   }
@@ -64,5 +66,7 @@ int main() {
   run<4>("ds_read_b64, 8 B/lane linear", out, cyc);
   run<5>("ds_read_b32, 4 B/lane linear", out, cyc);
   run<6>("ds_write_b128, one active lane", out, cyc);
+  run<7>("ds_swizzle_b32 (and 0x13 | 0x4: quad broadcast in a row)", out, cyc);
+  run<8>("ds_bpermute_b32, rotation by one lane (no sharing)", out, cyc);
   return 0;
 }
