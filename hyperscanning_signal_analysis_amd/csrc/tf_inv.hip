@@ -83,7 +83,7 @@ struct TfLds {
 // complex matrices Zin[item][f][MP][MP] (partial coherence of a spectral matrix, mtmvar.py:287-338), which
 // also returns the unit-modulus phase of the determinant (product of the pivots, sign of the interchanges).
 template <int NT, bool GEN>
-__global__ void __launch_bounds__(64 * NT, (NT == 4) ? 5 : 2) tf_inv_kernel(TfArgs a) {
+__global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfArgs a) {
   constexpr int MP = 16 * NT, NG = NT, NSTEP = MP / 4;
   using L = TfLds<NT>;
   constexpr int NR = L::NRING;
