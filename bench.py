@@ -174,7 +174,7 @@ def main():
                        "windows_per_step_per_gpu": n_windows, "k2_streams": 2 if two_streams else 1,
                        "parallelism": f"dyad-sharded x{world}",
                        "gather": "band-integrated ffDTF to rank 0 (once, timed)" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4> (K3)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4, false> (K3)", "achieved": achieved,
                          "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
                          "traffic": traffic, "k3_ms_per_launch": k3_ms,
                          "flop_per_launch": FLOP_K3_WINDOW * k3_windows, "windows_per_launch": k3_windows},

@@ -53,6 +53,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    # A/B measurements of kernel variants on ONE box: HYPERMVAR_LIB names another build of the same library
+    LIB_PATH = os.environ.get("HYPERMVAR_LIB", LIB_PATH)
     if not os.path.exists(LIB_PATH):
         raise HypermvarLibraryError(
             f"{LIB_PATH} not found: build the HIP library first "

@@ -73,7 +73,7 @@ try:
 except SystemExit as e:
     print("no SQ pass:", e)
 
-k3 = "hmv::tf_inv_kernel<4>"
+k3 = "hmv::tf_inv_kernel<4, false>"
 fetch, write = per_kernel["FETCH_SIZE"][k3], per_kernel["WRITE_SIZE"][k3]
 W = 599
 traffic = {
