@@ -252,6 +252,23 @@ def test_analytic_properties():
     assert rel(ffp, ff[perm][:, perm]) < 1e-9
 
 
+def test_ar_coefficient_recovery_on_long_var():
+    """Known-answer: a long realisation of a stable VAR(2) gives back its coefficients and innovation variance."""
+    rng = np.random.default_rng(21)
+    m, n = 5, 200_000
+    A1 = 0.4 * np.eye(m) + 0.08 * rng.standard_normal((m, m))
+    A2 = -0.25 * np.eye(m) + 0.05 * rng.standard_normal((m, m))
+    e = rng.standard_normal((n, m)) * np.array([1.0, 0.5, 2.0, 1.5, 0.8])
+    x = np.zeros((n, m))
+    for t in range(2, n):
+        x[t] = A1 @ x[t - 1] + A2 @ x[t - 2] + e[t]
+    ar, V = M.ar_coeff(np.ascontiguousarray(x.T), 2)
+    assert np.abs(ar[:, :, 0] - A1).max() < 2e-2 and np.abs(ar[:, :, 1] - A2).max() < 2e-2
+    assert np.abs(np.diag(V) - np.array([1.0, 0.25, 4.0, 2.25, 0.64])).max() < 5e-2
+    aro, Vo = O.ar_coeff(np.ascontiguousarray(x.T), 2)
+    assert_parity(ar, aro, 1e-9); assert_parity(V, Vo, 1e-9)
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_northstar_full_size_properties():
     """BASELINE.json config 1 sizes (m=64, p=8, F=256, 2 s windows, 50 % overlap) on 60 s of dyad 0:
