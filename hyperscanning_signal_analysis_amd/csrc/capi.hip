@@ -194,6 +194,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
   if (n <= p) return fail(-3, "hmv_sliding_ffdtf_f64: window shorter than the model order");
+  if (n_items == 0) return 0;                                    // empty batch: nothing to do, nothing to check
   if (!x || !item_rec || !item_start || !freqs || !ffdtf || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
   const SlidingWs w = sliding_layout(chunk, mp, p, F);

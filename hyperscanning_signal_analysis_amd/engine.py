@@ -229,6 +229,11 @@ class Engine:
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
+        if n_items == 0:                      # empty batch (torch gives empty tensors a null data pointer)
+            empty = self.empty(0, m, m, F)
+            if return_ar:
+                return empty, self.empty(0, mp, mp, p), self.empty(0, mp, mp), (self.empty(0, dtype=torch.int32),) * 2
+            return empty
         chunk = self.sliding_chunk(n_items, m, p, F) if chunk is None else int(chunk)
         nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F))
         ws = self._workspace(nbytes)

@@ -332,3 +332,27 @@ def test_multi_dyad_batch_matches_single_dyad_runs():
         assert torch.equal(alone, batch[d])
     ref = O.full_freq_dtf(xs[2][:, 500 * 5:500 * 5 + w], freqs, fs, p)
     assert_parity(batch[2, 5].cpu().numpy(), ref)
+
+
+def test_edge_cases_empty_single_and_ragged_batches():
+    """Empty batch, one window, a chunk larger than the batch, windows of several recordings with irregular
+    starts (what `_create_windows` produces when n_windows does not divide the recording), F = 1."""
+    eng = default_engine()
+    x = synthetic_var_dyad(3, T=6_000)
+    xd = eng.to_device(np.stack([x, x[::-1].copy()]))                  # two recordings
+    freqs = northstar_freqs(8)
+    empty_rec = torch.zeros(0, dtype=torch.int64, device=eng.device)
+    out0 = eng.sliding_ffdtf(xd, empty_rec, empty_rec, 1000, 4, freqs, 500.0)
+    assert out0.shape == (0, 64, 64, 8)
+    rec = torch.tensor([0, 1, 1, 0, 0], dtype=torch.int64, device=eng.device)
+    st = torch.tensor([0, 17, 4999, 3333, 5000], dtype=torch.int64, device=eng.device)     # last ones end at T
+    a = eng.sliding_ffdtf(xd, rec, st, 1000, 4, freqs, 500.0, chunk=64)
+    b = eng.sliding_ffdtf(xd, rec, st, 1000, 4, freqs, 500.0, chunk=2)
+    assert torch.equal(a, b)
+    xs = np.stack([x, x[::-1].copy()])
+    for k in range(5):
+        r, s = int(rec[k]), int(st[k])
+        assert_parity(a[k].cpu().numpy(), O.full_freq_dtf(xs[r][:, s:s + 1000], freqs, 500.0, 4), 1e-8)
+    one = eng.sliding_ffdtf(xd, rec[:1], st[:1], 1000, 4, freqs[:1], 500.0)                 # one window, F = 1
+    assert one.shape == (1, 64, 64, 1)
+    assert_parity(one[0].cpu().numpy(), O.full_freq_dtf(xs[0][:, :1000], freqs[:1], 500.0, 4), 1e-8)
