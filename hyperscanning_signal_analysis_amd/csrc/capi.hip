@@ -155,6 +155,26 @@ int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, i
   return hmv::launch_gpdc(A, V, G, n_items, F, m, mp, S(stream));
 }
 
+int64_t hmv_psd_workspace_bytes(int64_t ch_chunk, int64_t n_times, int n_tapers) {
+  if (ch_chunk < 1 || n_times < 2 || n_tapers < 1) return -1;
+  return (int64_t)hmv::psd_workspace_bytes(ch_chunk, n_times, n_tapers);
+}
+
+int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64_t ld, const double* tapers,
+                           const double* weights, int n_tapers, int64_t bin_lo, int64_t bin_hi, double* psd,
+                           void* workspace, int64_t workspace_bytes, int64_t ch_chunk, void* stream) {
+  if (!x || !tapers || !weights || !psd || !workspace) return fail(-4, "hmv_psd_multitaper_f64: null pointer");
+  if (n_ch < 0 || n_times < 2 || n_times > 0x7fffffff || n_tapers < 1 || ch_chunk < 1 || ld < n_times)
+    return fail(-2, "hmv_psd_multitaper_f64: bad size");
+  if (bin_lo < 0 || bin_hi < bin_lo || bin_hi > n_times / 2) return fail(-3, "hmv_psd_multitaper_f64: bad frequency bins");
+  if (workspace_bytes < hmv::psd_workspace_bytes(ch_chunk, n_times, n_tapers))
+    return fail(-7, "hmv_psd_multitaper_f64: workspace too small");
+  const int rc = hmv::launch_psd(x, n_ch, n_times, ld, tapers, weights, n_tapers, bin_lo, bin_hi, psd, workspace, ch_chunk,
+                                 S(stream));
+  if (rc <= -20) return fail(rc, "hmv_psd_multitaper_f64: hipFFT plan / execution failed");
+  return rc;
+}
+
 // ---- fused sliding-window path ----------------------------------------------------------------------
 namespace {
 struct SlidingWs {

@@ -84,4 +84,9 @@ int launch_pack_c128(const double* in, double* out, long long n_items, int F, in
 int launch_pcoh(const double* Sinv, const double* detph, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
 int launch_gpdc(const double* A, const double* V, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
 
+// ---- multitaper PSD (psd.hip; hipFFT for the transforms) -------------------------------------------------
+long long psd_workspace_bytes(long long ch_chunk, long long n, int K);
+int launch_psd(const double* x, long long n_ch, long long n, long long ld, const double* tapers, const double* w, int K,
+               long long lo, long long hi, double* psd, void* workspace, long long ch_chunk, hipStream_t st);
+
 }  // namespace hmv

@@ -101,6 +101,19 @@ int hmv_partial_coherence_c128(const double* Sinv, const double* detph, double* 
                                int F, void* stream);
 int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, int m, int F, void* stream);
 
+/* Multitaper PSD.  Replaces compute_psd_multitaper (src/psd.py:7-33), i.e.
+ * mne.time_frequency.psd_array_multitaper(data, sfreq, fmin, fmax, bandwidth) of mne==1.11.0 with its defaults
+ * (remove_dc, non-adaptive eigenvalue weights, normalization "length").  mne is NOT available offline: PARITY
+ * UNPINNED -- the algorithm is restated from its published description and checked against an independent
+ * NumPy restatement only.  x: [n_ch][ld] (n_times samples used), tapers: [n_tapers][n_times] DPSS windows and
+ * weights[k] = sqrt(eigenvalue_k) from the host (scipy.signal.windows.dpss), bins bin_lo..bin_hi of the
+ * one-sided spectrum (freq = bin * sfreq / n_times); psd: [n_ch][bin_hi - bin_lo + 1].  Transforms by hipFFT;
+ * plans are cached per (n_times, batch).  workspace: hmv_psd_workspace_bytes(ch_chunk, n_times, n_tapers). */
+int64_t hmv_psd_workspace_bytes(int64_t ch_chunk, int64_t n_times, int n_tapers);
+int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64_t ld, const double* tapers,
+                           const double* weights, int n_tapers, int64_t bin_lo, int64_t bin_hi, double* psd,
+                           void* workspace, int64_t workspace_bytes, int64_t ch_chunk, void* stream);
+
 /* Fused sliding-window path K1 -> K2 -> K3 -> K4 over all items, processed `chunk` items at a time so the
  * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].

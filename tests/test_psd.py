@@ -1,0 +1,59 @@
+"""Multitaper PSD.  PARITY UNPINNED: mne==1.11.0, which holds the arithmetic of the
+reference's `compute_psd_multitaper` (src/psd.py:30-32), is not available offline and the reference stores no
+output of it.  What is checked: the CPU restatement against analytic properties (CPU), and the GPU path (hipFFT +
+HIP kernels through the C ABI) against that restatement (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import psd_oracle as P
+
+
+def _signal(n_ch=5, n=6000, fs=500.0, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    x = rng.standard_normal((n_ch, n)) + 3.0
+    x[1] += 4.0 * np.sin(2 * np.pi * 10.0 * t)
+    return x, fs
+
+
+def test_oracle_properties_cpu():
+    x, fs = _signal()
+    freqs, psd = P.compute_psd_multitaper(x, fs, 1.0, 30.0, 2.0)
+    assert psd.shape == (5, len(freqs)) and freqs[0] >= 1.0 and freqs[-1] <= 30.0
+    assert np.all(psd > 0)
+    assert abs(freqs[np.argmax(psd[1])] - 10.0) <= 1.0                 # the 10 Hz line, smeared by the 2 Hz bandwidth
+    # white noise of unit variance: one-sided density per bin equals 2 (normalization 'length', no /sfreq);
+    # averaged over the band and the noise channels it is within a few percent
+    assert abs(psd[[0, 2, 3, 4]].mean() / 2.0 - 1.0) < 0.12
+    # the mean is removed, scaling is quadratic, channels are independent
+    f2, p2 = P.compute_psd_multitaper(3.0 * x + 100.0, fs, 1.0, 30.0, 2.0)
+    assert np.allclose(p2, 9.0 * psd, rtol=1e-9)
+    tapers, eig = P.mt_params(6000, fs, 2.0)
+    assert tapers.shape[0] == len(eig) and np.all(eig > 0.9) and len(eig) >= 20
+    assert np.allclose((tapers ** 2).sum(axis=1), 1.0, atol=2e-3)       # unit energy up to the periodic-window truncation
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ch,n,fs,bw", [(5, 6000, 500.0, 2.0), (19, 4097, 128.0, 1.0), (2, 30_001, 500.0, 2.0)])
+def test_gpu_psd_matches_restatement(n_ch, n, fs, bw):
+    from hyperscanning_signal_analysis_amd.psd import compute_psd_multitaper
+    x, _ = _signal(n_ch, n, fs, seed=n_ch)
+    freqs, psd = compute_psd_multitaper(x, fs, 1.0, 30.0, bw)
+    fo, po = P.compute_psd_multitaper(x, fs, 1.0, 30.0, bw)
+    assert np.array_equal(freqs, fo)
+    assert np.abs(psd - po).max() <= 1e-9 * np.abs(po).max()
+    assert np.allclose(psd, po, rtol=1e-7, atol=1e-12 * np.abs(po).max())
+
+
+@pytest.mark.gpu
+def test_gpu_psd_chunked_channels_and_edges():
+    from hyperscanning_signal_analysis_amd.psd import average_psd_across_conditions, compute_psd_multitaper
+    x, fs = _signal(7, 3000, 250.0, seed=9)
+    f1, p1 = compute_psd_multitaper(x, fs, 0.0, 125.0, 2.0)                       # DC and Nyquist bins included
+    f2, p2 = compute_psd_multitaper(x, fs, 0.0, 125.0, 2.0, max_workspace_bytes=1)  # one channel per chunk
+    assert np.array_equal(p1, p2)
+    fo, po = P.compute_psd_multitaper(x, fs, 0.0, 125.0, 2.0)
+    assert np.abs(p1 - po).max() <= 1e-9 * np.abs(po).max()
+    assert np.allclose(average_psd_across_conditions({"a": p1, "b": 3 * p1}), 2 * p1)
+    with pytest.raises(ValueError):
+        average_psd_across_conditions({})
