@@ -27,7 +27,7 @@
 //         blocks to the start of step s+1 (N_s stays valid in a ring of three buffers),
 //       - the other waves apply the interchanges of step s (rare; through LDS) and the rank-4 update
 //         M <- M + (N_s - E_S) * M[S, :] of their four blocks on the matrix pipe (A operand from LDS, B operand
-//         = the pivot rows by one ds_bpermute inside the 16-lane row); the owner of panel s replaces its
+//         = the pivot rows by one ds_swizzle inside the 16-lane row); the owner of panel s replaces its
 //         panel block by N_s instead of updating it,
 //       - one workgroup barrier per step.
 //     The serial factorisation (the critical path) thus overlaps the other waves' MFMA work, and every wave

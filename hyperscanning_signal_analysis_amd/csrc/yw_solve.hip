@@ -46,75 +46,6 @@ struct YwCfg {
   static constexpr int S = (MP <= 38) ? 38 : 70;   // >= MP and = 6 (mod 32)
 };
 
-// In-register inverse of a symmetric positive definite MP x MP tile held by ONE wave in the D layout.
-template <int NT>
-__device__ __forceinline__ void spd_inverse_wave(double (&t)[4 * NT][NT], double* Pb, double* Nb, int& info,
-                                                 double& logdet, bool want_logdet) {
-  constexpr int MP = 16 * NT, NI = 4 * NT, NJ = NT, NSTEP = MP / 4;
-  const int l = lane_id();
-  const int i = l >> 4, cc = l & 15;
-  double mypiv = 1.0;   // lane c keeps pivot c; ONE log per lane after the sweep (log() inlined per column
-                        // costs ~100 VGPRs and thousands of instructions)
-  static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int Js = s >> 2, q = s & 3;
-    if ((cc >> 2) == q) {
-#pragma unroll
-      for (int I = 0; I < NI; ++I) Pb[(4 * I + i) * 4 + (cc & 3)] = t[I][Js];
-    }
-    HMV_WAVE_SYNC();
-    double x[4];
-    {
-      const int r = (l < MP) ? l : 0;
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) x[jj] = Pb[r * 4 + jj];
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int col = 4 * s + jj;
-      const double piv = readlane_f64(x[jj], col);
-      if (!(piv > 0.0) && info == 0) info = col + 1;
-      mypiv = (l == col) ? piv : mypiv;
-      const double inv = 1.0 / piv;
-      double qv[4];
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) qv[j2] = (j2 == jj) ? inv : readlane_f64(x[j2], col) * inv;
-      const double f = x[jj];
-      const bool isp = (l == col);
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) {
-        const double tr = f * qv[j2];
-        const double nr = (j2 == jj) ? -tr : x[j2] - tr;
-        x[j2] = isp ? qv[j2] : nr;
-      }
-    }
-    if (l < MP) {
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) Nb[l * 4 + jj] = x[jj];
-    }
-    HMV_WAVE_SYNC();
-    double u[NJ];
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) u[J] = t[s][J];
-#pragma unroll
-    for (int I = 0; I < NI; ++I) {
-      double nv = Nb[(4 * I + (l & 3)) * 4 + (l >> 4)];
-      if (I == s) nv -= ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) t[I][J] = mfma4(nv, u[J], t[I][J]);
-    }
-    if ((cc >> 2) == q) {
-#pragma unroll
-      for (int I = 0; I < NI; ++I) t[I][Js] = Nb[(4 * I + i) * 4 + (cc & 3)];
-    }
-    HMV_WAVE_SYNC();
-  });
-  if (want_logdet) {
-    double v = row16_sum_dpp(log(mypiv));          // padded lanes hold 1.0 -> log = 0
-    logdet = readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
-  }
-}
-
 // Cooperative inverse of the symmetric positive definite MP x MP tile stored row-major (stride S) in LDS
 // `Xs`, by the whole workgroup (same scheme as K3, real arithmetic, no pivoting): wave w < NT holds columns
 // 16w..16w+15 in the D layout; the wave that owns the 4 panel columns of block step s factors them in a
