@@ -356,3 +356,30 @@ def test_edge_cases_empty_single_and_ragged_batches():
     one = eng.sliding_ffdtf(xd, rec[:1], st[:1], 1000, 4, freqs[:1], 500.0)                 # one window, F = 1
     assert one.shape == (1, 64, 64, 1)
     assert_parity(one[0].cpu().numpy(), O.full_freq_dtf(xs[0][:, :1000], freqs[:1], 500.0, 4), 1e-8)
+
+
+def test_connectivity_kernels_batched_and_singular():
+    """The rank-4 kernels over a batch of windows equal the per-window results bit for bit, and a singular
+    spectral matrix raises like np.linalg (the reference would divide by a zero minor product instead)."""
+    eng = default_engine()
+    rng = np.random.default_rng(12)
+    m, F, W = 6, 5, 4
+    freqs = np.linspace(2.0, 30.0, F)
+    x = rng.standard_normal((W, m, 500))
+    x[:, :, 1:] += 0.5 * x[:, :, :-1]
+    xd = eng.to_device(x)
+    rec = torch.arange(W, dtype=torch.int64, device=eng.device)
+    st = torch.zeros(W, dtype=torch.int64, device=eng.device)
+    R = eng.lagcov(xd, rec, st, 500, 3)
+    ar, V, _, _ = eng.yw_solve(R, m)
+    t = eng.transfer(ar, m, eng.twiddles(freqs, 100.0, 3), want_P=False, want_H=True, want_A=True)
+    S = eng.spectra(t["H"], V, m)
+    kap, info = eng.partial_coherence(S, m)
+    g = eng.gpdc(t["A"], V, m)
+    assert kap.shape == (W, m, m, F) and g.shape == (W, m, m, F) and not bool(info.any())
+    for k in range(W):
+        res = M.mvar_analysis(x[k], freqs, 100.0, 3, want=("pcoh", "gpdc"))
+        assert np.array_equal(kap[k].cpu().numpy(), res["pcoh"]) and np.array_equal(g[k].cpu().numpy(), res["gpdc"])
+    Z = np.ones((3, 3, 2), dtype=complex)                     # rank one: every 2x2 minor vanishes
+    with pytest.raises(np.linalg.LinAlgError):
+        M.partial_coherence(Z)
