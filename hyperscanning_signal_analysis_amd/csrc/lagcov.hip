@@ -23,7 +23,7 @@ constexpr int LC_S = LC_TC + LC_HALO + 6;   // 102 = 6 (mod 32)
 // MP x MP accumulator (NT row blocks x NT column groups = NT*NT accumulators per lane), so every lag gets
 // the same four waves and no wave idles when p+1 is not a multiple of four.
 template <int NT>
-__global__ void __launch_bounds__(256, 3) lagcov_kernel(LagcovArgs a) {
+__global__ void __launch_bounds__(256, 4) lagcov_kernel(LagcovArgs a) {
   constexpr int MP = 16 * NT, NIW = NT, NJ = NT;
   __shared__ double xs[MP * LC_S];
   const int l = lane_id();
