@@ -1,0 +1,16 @@
+"""Host-side context for bench.py's cpu_baseline: the vectorised NumPy restatement (batched np.linalg.inv over the
+frequencies) next to the reference-loop-structured port, single process, on windows of the north-star dyad."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mvar_oracle as O
+from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad, northstar_freqs
+x = synthetic_var_dyad(0, T=20_000)
+freqs = northstar_freqs(256)
+for name, fn, nwin in (("loop-structured port (as bench.py)", O.full_freq_dtf_loop, 12), ("vectorised restatement", O.full_freq_dtf, 24)):
+    t0 = time.perf_counter()
+    for k in range(nwin):
+        fn(x[:, 500 * k:500 * k + 1000], freqs, 500.0, 8)
+    dt = time.perf_counter() - t0
+    print(f"{name}: {nwin / dt:.1f} windows/s on {os.cpu_count()} visible cores (BLAS threads: default)")
