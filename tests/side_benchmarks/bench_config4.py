@@ -2,7 +2,7 @@
 p = 5, 30 frequencies) as one GPU batch -- ffDTF only (fused C call) and ffDTF + spectra (staged calls)."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hyperscanning_signal_analysis_amd.engine import Engine
 

@@ -3,7 +3,7 @@ at the north-star shape (m = 64, n = 1000, p = 8, F = 256) on the GPU, and at m 
 minors-by-determinant algorithm (oracle restatement) on the host."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hyperscanning_signal_analysis_amd.engine import Engine
 from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad, northstar_freqs

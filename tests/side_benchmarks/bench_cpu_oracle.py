@@ -2,7 +2,7 @@
 frequencies) next to the reference-loop-structured port, single process, on windows of the north-star dyad."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import mvar_oracle as O
 from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad, northstar_freqs

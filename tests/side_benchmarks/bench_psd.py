@@ -2,7 +2,7 @@
 fmin 1, fmax 30, bandwidth 2 Hz -> 439 tapers) on the GPU, and the NumPy restatement on a few channels."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hyperscanning_signal_analysis_amd.psd import compute_psd_multitaper, _tapers
 
