@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
   // matrix (one contiguous 32 KB region per f) instead of touching it 64 times far apart in time
   const int i = blockIdx.x % m;
   const long long tile_id = blockIdx.x / m;
-  const long long item = tile_id / nft;
+  // newest first: K3 wrote the items in ascending order, the last ones may still sit in the memory-side cache
+  const long long item = a.n_items - 1 - tile_id / nft;
   const int f0 = (int)(tile_id % nft) * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const double* P = a.P + ((size_t)item * F * MP + (size_t)i) * MP;   // + f*MP*MP + j
