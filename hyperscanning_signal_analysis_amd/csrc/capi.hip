@@ -3,6 +3,7 @@
 #include "hmv_kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -83,7 +84,7 @@ int hmv_tf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw
   if (!ar || !tw || !info || !ws || n_items < 0 || F < 0) return fail(-4, "hmv_tf_f64: null pointer");
   if ((P == nullptr) != (rowsum == nullptr)) return fail(-5, "hmv_tf_f64: P and rowsum go together");
   if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_f64: pivot_tau must be in (0, 1]");
-  hmv::TfArgs a;
+  hmv::TfArgs a{};
   a.ar = ar; a.arx = ws; a.tw = tw; a.Zin = nullptr; a.detph = nullptr; a.P = P; a.rowsum = rowsum; a.H = H; a.A = A; a.info = info;
   a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   a.stamps = nullptr;
@@ -133,7 +134,7 @@ int hmv_cinv_c128(const double* Z, int64_t n_items, int m, int F, double* Zinv, 
   if (mp < 0) return fail(-1, "hmv_cinv_c128: channel count must be in 1..64");
   if (!Z || !Zinv || !info || n_items < 0 || F < 0) return fail(-4, "hmv_cinv_c128: null pointer");
   if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_cinv_c128: pivot_tau must be in (0, 1]");
-  hmv::TfArgs a;
+  hmv::TfArgs a{};
   a.ar = nullptr; a.arx = nullptr; a.tw = nullptr; a.Zin = Z; a.detph = detph; a.P = nullptr; a.rowsum = nullptr;
   a.H = Zinv; a.A = nullptr; a.info = info; a.n_items = n_items; a.F = F; a.p = 0; a.m = m; a.tau = pivot_tau;
   a.stamps = nullptr;
@@ -175,10 +176,87 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
   return rc;
 }
 
+// ---- K3 with the ffDTF normalisation folded in ------------------------------------------------------
+namespace {
+struct TfFfWs {
+  size_t off_arx, off_P, off_rowsum, off_cnt, total;
+};
+TfFfWs tf_ff_layout(int64_t n, int mp, int p, int F) {
+  TfFfWs w;
+  size_t o = 0;
+  const size_t t = (size_t)mp * mp;
+  w.off_arx = o;    o += align256(sizeof(double) * hmv::tf_workspace_doubles(n, mp, p));
+  w.off_P = o;      o += align256(sizeof(double) * n * F * t);
+  w.off_rowsum = o; o += align256(sizeof(double) * n * F * mp);
+  w.off_cnt = o;    o += align256(sizeof(int) * (2 * n + 1 + n * mp));     // wcount, ready, missed (TfArgs)
+  w.total = o;
+  return w;
+}
+// Rows of window w are normalised inside K3 by workgroups of window w + lag, and the last `lag` windows of a batch
+// by the separate K4 pass.  lag = six times the number of windows the chip holds at once (resident workgroups /
+// F): at the north-star shape (4 windows resident) lag 8 left a third of the rows unfinished when they came up,
+// 16 a tenth, 24 none (profiles/r02_norm_lag_sweep.txt).  A row that comes up too early is not waited for (it goes
+// to norm_missed_kernel), so this only tunes speed.
+int64_t norm_lag_items(int mp, int F) {
+  const int64_t slots = (mp == 64 || mp == 48) ? 1024 : (mp == 32 ? 2048 : 5120);
+  int64_t lag = (6 * slots + F - 1) / (F < 1 ? 1 : F);
+  if (const char* e = getenv("HYPERMVAR_NORM_LAG")) lag = atoll(e);      // tuning experiments only
+  return lag < 8 ? 8 : lag;
+}
+}  // namespace
+
+int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F) {
+  const int mp = pad_of(m);
+  if (mp < 0 || n_items < 0 || p < 1 || F < 1) return -1;
+  return (int64_t)tf_ff_layout(n_items, mp, p, F).total;
+}
+
+int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* ffdtf,
+                     double* den, int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes,
+                     int64_t flags, void* ev_k3_start, void* ev_k3_stop, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_tf_ffdtf_f64: channel count must be in 1..64");
+  if (p < 1) return fail(-2, "hmv_tf_ffdtf_f64: model order must be >= 1");
+  if (n_items == 0) return 0;
+  if (!ar || !tw || !ffdtf || !den || !info || !workspace || n_items < 0 || F < 1)
+    return fail(-4, "hmv_tf_ffdtf_f64: null pointer / empty grid");
+  if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_ffdtf_f64: pivot_tau must be in (0, 1]");
+  const TfFfWs w = tf_ff_layout(n_items, mp, p, F);
+  if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_tf_ffdtf_f64: workspace too small");
+  char* base = static_cast<char*>(workspace);
+  const size_t t = (size_t)mp * mp;
+  hmv::TfArgs a{};
+  a.ar = ar; a.arx = reinterpret_cast<double*>(base + w.off_arx); a.tw = tw;
+  a.P = reinterpret_cast<double*>(base + w.off_P); a.rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+  a.info = info; a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
+  // the in-kernel normaliser moves 16 bytes per lane: whole 16-frequency lines of a 16-byte aligned output
+  const bool fused = !(flags & HMV_FLAG_UNFUSED_NORM) && (F % 16 == 0) && (reinterpret_cast<uintptr_t>(ffdtf) % 16 == 0);
+  const int64_t lag = norm_lag_items(mp, F);
+  const int64_t n_fused = (fused && n_items > lag) ? n_items - lag : 0;
+  if (n_fused > 0) {
+    a.ff = ffdtf; a.den = den; a.fuse_items = n_fused; a.lag = (int)lag;
+    a.wcount = reinterpret_cast<int*>(base + w.off_cnt);
+    a.ready = a.wcount + n_items;
+    a.missed = a.ready + n_items;
+  }
+#ifdef HMV_STAMP
+  a.stamps = g_tf_stamps;
+#endif
+  hipStream_t st = S(stream);
+  if (ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st);
+  int rc = hmv::launch_tf_inv(a, mp, st);
+  if (ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st);
+  if (rc) return rc;
+  if (n_fused < n_items)
+    rc = hmv_ffdtf_norm_f64(a.P + (size_t)n_fused * F * t, a.rowsum + (size_t)n_fused * F * mp, den + (size_t)n_fused * mp,
+                            ffdtf + (size_t)n_fused * m * m * F, n_items - n_fused, F, m, 1, stream);
+  return rc;
+}
+
 // ---- fused sliding-window path ----------------------------------------------------------------------
 namespace {
 struct SlidingWs {
-  size_t off_R, off_ws, off_ar, off_arx, off_V, off_P, off_rowsum, off_den, off_tw, total;
+  size_t off_R, off_ws, off_ar, off_V, off_tf, off_den, off_tw, total;
 };
 SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   SlidingWs w;
@@ -187,14 +265,28 @@ SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   w.off_R = o;      o += align256(sizeof(double) * chunk * (p + 1) * t);
   w.off_ws = o;     o += align256(sizeof(double) * chunk * hmv::yw_ws_tiles(p) * t);
   w.off_ar = o;     o += align256(sizeof(double) * chunk * t * p);
-  w.off_arx = o;    o += align256(sizeof(double) * hmv::tf_workspace_doubles(chunk, mp, p));
   w.off_V = o;      o += align256(sizeof(double) * chunk * t);
-  w.off_P = o;      o += align256(sizeof(double) * chunk * F * t);
-  w.off_rowsum = o; o += align256(sizeof(double) * chunk * F * mp);
+  w.off_tf = o;     o += tf_ff_layout(chunk, mp, p, F).total;
   w.off_den = o;    o += align256(sizeof(double) * chunk * mp);
   w.off_tw = o;     o += align256(sizeof(double) * F * p * 2);
   w.total = o;
   return w;
+}
+// Fork / join events of the two-stream K2 split: created once per (host thread, device), not per call.
+struct ForkJoin {
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+ForkJoin* fork_join_events() {
+  constexpr int MAXDEV = 64;
+  thread_local ForkJoin tl[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  ForkJoin& e = tl[dev];
+  if (!e.fork) {
+    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &e;
 }
 }  // namespace
 
@@ -208,8 +300,8 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
                           const int64_t* item_start, int64_t n_items, int m, int n, int p,
                           const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
-                          int64_t chunk, double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream,
-                          void* aux_stream) {
+                          int64_t chunk, double pivot_tau, int64_t flags, void* ev_k3_start, void* ev_k3_stop,
+                          void* stream, void* aux_stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
@@ -226,11 +318,10 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   // of chunk c) was measured and does NOT work: K3 holds every wave slot and starves the other stream.
   hipStream_t st0 = S(stream), st1 = S(aux_stream);
   const bool split = (aux_stream && aux_stream != stream);
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ForkJoin* fj = nullptr;
   if (split) {
-    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)
-      return fail(-8, "hmv_sliding_ffdtf_f64: cannot create fork/join events");
+    fj = fork_join_events();
+    if (!fj) return fail(-8, "hmv_sliding_ffdtf_f64: cannot create fork/join events");
   }
   int rc = 0;
   const size_t t = (size_t)mp * mp;
@@ -239,12 +330,11 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   double* R = reinterpret_cast<double*>(base + w.off_R);
   double* ws = reinterpret_cast<double*>(base + w.off_ws);
   double* ar = reinterpret_cast<double*>(base + w.off_ar);
-  double* arx = reinterpret_cast<double*>(base + w.off_arx);
   double* V = reinterpret_cast<double*>(base + w.off_V);
-  double* P = reinterpret_cast<double*>(base + w.off_P);
-  double* rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+  void* tfws = base + w.off_tf;
   double* den = reinterpret_cast<double*>(base + w.off_den);
   double* tw = reinterpret_cast<double*>(base + w.off_tw);
+  const int64_t tfws_bytes = (int64_t)tf_ff_layout(chunk, mp, p, F).total;
   rc = hmv_twiddles_f64(freqs, F, fs, p, tw, st0);
   const size_t ws_item = (size_t)hmv_yw_workspace_doubles(m, p);
   for (int64_t ci = 0; ci < n_chunks && rc == 0; ++ci) {
@@ -256,26 +346,19 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     if (rc) break;
     const int64_t c0 = (split && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
     if (c1 > 0) {
-      (void)hipEventRecord(ev_fork, st0);
-      (void)hipStreamWaitEvent(st1, ev_fork, 0);
+      (void)hipEventRecord(fj->fork, st0);
+      (void)hipStreamWaitEvent(st1, fj->fork, 0);
       rc = hmv_yw_solve_f64(R + (size_t)c0 * (p + 1) * t, c1, m, p, ws + (size_t)c0 * ws_item,
                             ar_c + (size_t)c0 * t * p, V_c + (size_t)c0 * t, nullptr, info_yw + i0 + c0, st1);
-      (void)hipEventRecord(ev_join, st1);
+      (void)hipEventRecord(fj->join, st1);
       if (rc) break;
     }
     rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, st0);
-    if (c1 > 0) (void)hipStreamWaitEvent(st0, ev_join, 0);
+    if (c1 > 0) (void)hipStreamWaitEvent(st0, fj->join, 0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
-    if (last && ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st0);
-    rc = hmv_tf_f64(ar_c, c, m, p, tw, F, P, rowsum, nullptr, nullptr, info_tf + (size_t)i0 * F, pivot_tau, arx, st0);
-    if (last && ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st0);
-    if (rc) break;
-    rc = hmv_ffdtf_norm_f64(P, rowsum, den, ffdtf + (size_t)i0 * m * m * F, c, F, m, 1, st0);
-  }
-  if (split) {
-    (void)hipEventDestroy(ev_fork);
-    (void)hipEventDestroy(ev_join);
+    rc = hmv_tf_ffdtf_f64(ar_c, c, m, p, tw, F, ffdtf + (size_t)i0 * m * m * F, den, info_tf + (size_t)i0 * F, pivot_tau,
+                          tfws, tfws_bytes, flags, last ? ev_k3_start : nullptr, last ? ev_k3_stop : nullptr, st0);
   }
   return rc;
 }

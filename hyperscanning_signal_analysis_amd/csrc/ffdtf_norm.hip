@@ -4,7 +4,8 @@
 //     ff[i, j, f] = dtf[i, j, f] / sum_{j', f'} dtf[i, j', f'].
 // K3 leaves P[item][f][i][j] = |H_ij(f)|^2 (kernel-natural layout, j contiguous) and the per-(f, i)
 // partial sums rowsum[item][f][i].  Here:
-//   den_kernel      den[item][i] = sum_f rowsum[item][f][i]   (fixed f order: bit-reproducible)
+//   den_kernel      den[item][i] = sum_f rowsum[item][f][i]   (fixed order: four ascending quarter sums, then
+//                   ((s0 + s1) + s2) + s3 -- bit-reproducible and identical to the fused normaliser of K3)
 //   norm_kernel     out[item][i][j][f] = P[item][f][i][j] / den[item][i]  via a 64(f) x 64(j) LDS tile so
 //                   that both the global reads (j contiguous) and the writes (f contiguous) are full
 //                   512-byte runs.  HBM-bound: 2 x 8 B per output element.
@@ -14,22 +15,32 @@
 
 namespace hmv {
 
-__global__ void __launch_bounds__(64) den_kernel(const double* rowsum, double* den, int F, int m_pad) {
+// block = 4 * m_pad threads: thread row q sums the q-th quarter of the frequency grid in ascending order, the
+// four partial sums are added in the fixed order ((s0 + s1) + s2) + s3 -- the same scheme as the normaliser
+// inside K3 (tf_inv.hip, window_denominators), so both give bit-identical denominators.
+__global__ void __launch_bounds__(256) den_kernel(const double* rowsum, double* den, int F, int m_pad) {
+  __shared__ double dpart[4 * 64];
   const long long item = blockIdx.x;
-  const int i = threadIdx.x;
-  if (i >= m_pad) return;
+  const int ty = threadIdx.x / m_pad, i = threadIdx.x - ty * m_pad;
   const double* rs = rowsum + (size_t)item * F * m_pad + i;
+  const int fq = (F + 3) >> 2;
+  const int f1 = min(F, (ty + 1) * fq);
   double acc = 0.0;
-  int f = 0;
-  for (; f + 16 <= F; f += 16) {          // 16 loads in flight, summed in the fixed order f = 0, 1, 2, ...
+  int f = ty * fq;
+  for (; f + 16 <= f1; f += 16) {          // 16 loads in flight, summed in ascending f
     double v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = rs[(size_t)(f + k) * m_pad];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc += v[k];
   }
-  for (; f < F; ++f) acc += rs[(size_t)f * m_pad];
-  den[(size_t)item * m_pad + i] = acc;
+  for (; f < f1; ++f) acc += rs[(size_t)f * m_pad];
+  dpart[ty * m_pad + i] = acc;
+  __syncthreads();
+  if (threadIdx.x < m_pad) {
+    const int t = threadIdx.x;
+    den[(size_t)item * m_pad + t] = ((dpart[t] + dpart[m_pad + t]) + dpart[2 * m_pad + t]) + dpart[3 * m_pad + t];
+  }
 }
 
 // grid: ceil(F/64) * n_items * m; block 256
@@ -57,8 +68,10 @@ __global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = stage[k];
   __syncthreads();
-  double scale_den = 1.0;
-  if (a.normalise) scale_den = a.den[(size_t)item * MP + i];
+  // one reciprocal per output row, one multiply per element (the normaliser fused into K3 does exactly the same,
+  // so both paths give the same bits; against a true division this is <= 1.5 ulp)
+  double scale = 1.0;
+  if (a.normalise) scale = 1.0 / a.den[(size_t)item * MP + i];
   double* out = a.out + (((size_t)item * m + i) * m) * F;             // + j*F + f
 #pragma unroll
   for (int r = ty; r < 64; r += 4) {
@@ -66,7 +79,7 @@ __global__ void __launch_bounds__(256) norm_kernel(NormArgs a) {
     const int f = f0 + tx;
     if (j < m && f < F) {
       const double v = tile[tx][j];
-      __builtin_nontemporal_store(a.normalise ? v / scale_den : v, out + (size_t)j * F + f);
+      __builtin_nontemporal_store(v * scale, out + (size_t)j * F + f);
     }
   }
 }
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(256) transpose_c128_kernel(const double2* in, 
 int launch_ffdtf_norm(const NormArgs& a, hipStream_t st) {
   if (a.n_items == 0) return 0;
   if (a.normalise)
-    hipLaunchKernelGGL(den_kernel, dim3((unsigned)a.n_items), dim3(64), 0, st, a.rowsum, a.den, a.F, a.m_pad);
+    hipLaunchKernelGGL(den_kernel, dim3((unsigned)a.n_items), dim3(4 * a.m_pad), 0, st, a.rowsum, a.den, a.F, a.m_pad);
   const dim3 grid((unsigned)(((a.F + 63) / 64) * a.n_items * a.m));
   hipLaunchKernelGGL(norm_kernel, grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();

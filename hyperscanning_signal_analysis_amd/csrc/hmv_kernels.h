@@ -47,6 +47,16 @@ struct TfArgs {
   long long n_items;
   int F, p, m;
   double tau;               // pivot threshold: 1.0 = LAPACK partial pivoting
+  // ffDTF normalisation inside K3 (hot path only; ff == nullptr: off).  Items < fuse_items publish their |H|^2
+  // row-major and are normalised in-kernel, row i of item w by a workgroup of item w + lag; the caller runs K4
+  // on the items >= fuse_items.
+  double* ff;               // [n_items][m][m][F]
+  double* den;              // [n_items][MP]
+  int* wcount;              // [n_items] arrival counters          } one block of 2 * n_items + 1 ints that the
+  int* ready;               // [n_items] denominators are in place  } launcher zeroes, followed by the list
+  int* missed;              // [1 + fuse_items * MP] count, rows     } of rows left to norm_missed_kernel
+  long long fuse_items;
+  int lag;
   unsigned long long* stamps;   // diagnostic builds (-DHMV_STAMP) only: [wave][8] phase cycle sums; else null
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);

@@ -72,12 +72,155 @@ struct TfLds {
   static constexpr int NRING = 3;            // N_s is read during steps s and s+1, N_{s+1} written during s
   // double2 units
   static constexpr int PBUF = MP * 5;        // panel, row stride 80 B (conflict-free lane-per-row reads)
-  static constexpr int NBUF = MP * 4;        // N = M'[:, S], row stride 64 B
+  static constexpr int NBUF = MP * 4;        // N = M'[:, S], row stride 64 B (a bank-conflict-free swizzled image was
+                                             // measured 2 % SLOWER: profiles/r02_ab_notes.md)
   static constexpr int SROW = 8;             // pivot row + displaced row of the current pivot column
   static constexpr int SWAPB = NT * 32;      // per wave: two matrix-row segments of 16 columns
   static constexpr int RSUM = NT * MP / 2;   // per wave row-sum partials (doubles)
   static constexpr int TOTAL = PBUF + NRING * NBUF + SROW + SWAPB + RSUM;
 };
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// Device-scope write-through stores (global_store ... sc1): the bytes go to memory past the XCD's L2.
+// The s_nop 1 is the hazard slot hipcc pads by itself after its own stores and cannot see inside an asm
+// statement: a VMEM store of more than 64 bits reads its data VGPRs late, and a VALU write to them within the
+// next two wait states (gfx940 family) corrupts the stored value (found the hard way: m = 48 only, half of
+// every 16-byte store wrong in some windows).
+__device__ __forceinline__ void store_sc1_b128(double* p, f64x2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_sc1_b64(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// ---------------------------------------------------------------- ffDTF normalisation inside K3
+// out[i][j][f] = |H_ij(f)|^2 * (1 / den[i]),  den[i] = sum_{j,f} |H_ij(f)|^2   (mtmvar.py:281-283), from K3's own
+// outputs while the rest of the chip keeps inverting.  Same arithmetic and summation order as den_kernel /
+// norm_kernel (ffdtf_norm.hip): a window normalised here and one normalised by K4 are bit-identical.
+//
+// Who does it (all measured on the chip, profiles/r02_norm_trace_last_arriver.txt):
+//   * the workgroup whose arrival completes window w only adds up the denominators (128 KB of row sums) and
+//     raises ready[w].  Letting it normalise the whole window does NOT work: the completing workgroup always
+//     sits on the slowest XCD, normalising slows that XCD further, so ~97 % of all windows were normalised on ONE
+//     XCD, up to 37 at a time behind its ~0.55 TB/s path to memory -- K3 took 26 ms instead of 8.4;
+//   * output row i of window w is written by a FIXED workgroup of window w + lag (frequency slot f = i, i + F, ..)
+//     when it has finished its own matrix: blocks are dealt round-robin over XCDs and CUs, so the rows of every
+//     window spread over the whole chip, 256 KB of traffic per workgroup.  With in-order dispatch window w has
+//     long been complete by then; a workgroup that finds ready[w] still clear does not wait (no spin, no
+//     residency assumption): it appends the row to a list that norm_missed_kernel works off after K3.
+// What a row costs is instruction issue on SIMDs shared with three inverting workgroups, so the loop moves 16
+// bytes per lane and instruction (loads, LDS, stores), multiplies by one reciprocal, and has no workgroup barrier:
+// every wave transposes its own 16(f) x 32(j) tiles in a private LDS region (ds_write2_b64 / ds_read2_b64,
+// conflict-free with the odd row stride), four tiles in flight.  Published windows keep |H|^2 ROW-major over
+// frequency, Pp[item][i][f][j] (publish step of the kernel): the slab of one output row is F*MP contiguous
+// doubles.  Needs F % 16 == 0 and a 16-byte aligned output (the launcher checks; otherwise K4 does the job).
+template <int NT>
+struct NormLds {
+  static constexpr int MP = 16 * NT;
+  static constexpr int FC = 16, JC = (MP % 32 == 0) ? 32 : 16, TS = JC + 1;     // wave tile: FC frequencies x JC columns
+  static constexpr int DOUBLES = NT * FC * TS + 5 * MP;
+};
+
+// den[item][:] from the row sums of all frequencies; every thread of the workgroup; `lds`: NormLds doubles.
+template <int NT>
+__device__ __forceinline__ void window_denominators(const TfArgs& a, int item, double* lds) {
+  constexpr int MP = 16 * NT;
+  using N = NormLds<NT>;
+  double* dpart = lds + NT * N::FC * N::TS;      // [4][MP] partial sums over the four quarters of the grid
+  const int F = a.F, t = threadIdx.x;
+  const int ty = t / MP, tx = t - ty * MP;         // 64 * NT / MP = 4 thread rows
+  const double* rs = a.rowsum + (size_t)item * F * MP + tx;
+  const int fq = (F + 3) >> 2;
+  const int f1 = min(F, (ty + 1) * fq);
+  double acc = 0.0;
+  int f = ty * fq;
+  for (; f + 16 <= f1; f += 16) {     // 16 loads in flight, summed in ascending f
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = rs[(size_t)(f + k) * MP];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += v[k];
+  }
+  for (; f < f1; ++f) acc += rs[(size_t)f * MP];
+  dpart[ty * MP + tx] = acc;
+  __syncthreads();
+  if (t < MP) {
+    const double d = ((dpart[t] + dpart[MP + t]) + dpart[2 * MP + t]) + dpart[3 * MP + t];
+    store_sc1_b64(a.den + (size_t)item * MP + t, d);
+  }
+}
+
+// Output row i of window `item`; every thread of the workgroup, no workgroup barrier inside.
+template <int NT>
+__device__ __forceinline__ void normalise_row(const TfArgs& a, int item, int i, double* lds) {
+  constexpr int MP = 16 * NT;
+  using N = NormLds<NT>;
+  constexpr int FC = N::FC, JC = N::JC, TS = N::TS;
+  constexpr int J2 = JC / 2, FR = 64 / J2, NL = FC / FR, NQ = JC / 8, NJC = MP / JC, D = 4;
+  const int F = a.F, m = a.m;
+  const int l = threadIdx.x & 63, wv = uni(threadIdx.x >> 6);
+  double* tile = lds + wv * (FC * TS);     // this wave's private tile
+  const double r = 1.0 / __hip_atomic_load(a.den + (size_t)item * MP + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // wave-trips of this row: (16-frequency chunk, JC-column chunk), dealt round-robin to the waves
+  const int total = (F / FC) * NJC;
+  const int fr = l / J2, j2 = l - fr * J2;           // load side: FR frequency rows x J2 column pairs per instruction
+  const int f2 = l & 7, jr = l >> 3;                 // store side: 8 frequency pairs x 8 columns per instruction
+  const double* Pw = a.P + ((size_t)item * MP + i) * F * MP + (size_t)fr * MP + 2 * j2;     // Pp[item][i][f][j]
+  double* ow = a.ff + ((size_t)item * m + i) * m * F + (size_t)jr * F + 2 * f2;
+  auto issue = [&](f64x2 (&v)[NL], int u) __attribute__((always_inline)) {
+    if (u < total) {
+      const int jc = u % NJC, f0 = (u / NJC) * FC;
+      const double* src = Pw + (size_t)f0 * MP + jc * JC;
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src + (size_t)(k * FR) * MP));
+    }
+  };
+  auto drain = [&](const f64x2 (&v)[NL], int u) __attribute__((always_inline)) {
+    if (u < total) {
+      const int jc = u % NJC, f0 = (u / NJC) * FC, j0 = jc * JC;
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        double* w = tile + (fr + k * FR) * TS + 2 * j2;
+        w[0] = v[k].x;
+        w[1] = v[k].y;
+      }
+      HMV_LDS_FENCE();               // one wave: LDS operations execute in order, this only pins the compiler
+      double* dst = ow + (size_t)j0 * F + f0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const double x0 = tile[(2 * f2) * TS + jr + 8 * q], x1 = tile[(2 * f2 + 1) * TS + jr + 8 * q];
+        f64x2 o;
+        o.x = x0 * r;
+        o.y = x1 * r;
+        if (j0 + jr + 8 * q < m) __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(dst + (size_t)(8 * q) * F));
+      }
+      HMV_LDS_FENCE();
+    }
+  };
+  f64x2 buf[D][NL];
+  static_for<D>([&](auto dc) __attribute__((always_inline)) { issue(buf[decltype(dc)::value], wv + NT * decltype(dc)::value); });
+  for (int u = wv; u < total; u += NT * D) {
+    static_for<D>([&](auto dc) __attribute__((always_inline)) {
+      constexpr int d = decltype(dc)::value;
+      drain(buf[d], u + NT * d);
+      issue(buf[d], u + NT * (d + D));
+    });
+  }
+}
+
+// Rows that found their window unfinished inside K3 (a.missed[0] = how many, a.missed[1..] = item * MP + i).  Runs
+// after K3 on the same stream, so everything is visible; normally the list is empty.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
+  __shared__ double lds[NormLds<NT>::DOUBLES];
+  const int n = a.missed[0];
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    const int e = a.missed[1 + k];
+    normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds);
+    __syncthreads();
+  }
+}
 
 // GEN = false: A(f) from the AR coefficients (the hot path).  GEN = true: the same inversion of arbitrary
 // complex matrices Zin[item][f][MP][MP] (partial coherence of a spectral matrix, mtmvar.py:287-338), which
@@ -99,9 +242,11 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
   // workgroups run in near lockstep and wave k of every workgroup tends to sit on the same SIMD, so without
   // the rotation the resident panel factorisations (one wave each) pile up on one SIMD.
   const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;
-  const long long gw = blockIdx.x;              // item * F + f
+  // One workgroup = one (window, frequency) matrix.  (A runtime loop over several frequencies per workgroup
+  // was tried to amortise the publish step below: the loop-carried state costs 525 spilled VGPRs.)
   const int item = uni((int)(blockIdx.x / (unsigned)a.F));   // wave-uniform: keep it in SGPRs
   const int f = uni((int)(blockIdx.x - (unsigned)item * (unsigned)a.F));
+  const long long gw = (long long)item * a.F + f;
   const int p = a.p;
   // "X layout" (hmv_common.h lane maps with the four MFMA blocks on four ROW blocks): lane (i, b, j) holds
   // rows 16*Ig + 4*b + i and columns 4*(Jl*NT + w) + j in register [Ig][Jl].
@@ -514,27 +659,70 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
       for (int Jl = 0; Jl < 4; ++Jl) Ho[(size_t)(16 * Ig) * MP + oc[Jl]] = make_double2(re[Ig][Jl], im[Ig][Jl]);
   }
   if (a.P) {
-    double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
     double* rs = rsum + w * MP + rowo;
+    const bool publish = !GEN && a.ff != nullptr && item < a.fuse_items;     // workgroup-uniform
+    if (!publish) {
+      double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
 #pragma unroll
-    for (int Ig = 0; Ig < NG; ++Ig) {
-      double acc = 0.0;
+      for (int Ig = 0; Ig < NG; ++Ig) {
+        double acc = 0.0;
 #pragma unroll
-      for (int Jl = 0; Jl < 4; ++Jl) {
-        const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
-        Po[(size_t)(16 * Ig) * MP + oc[Jl]] = v;
-        acc += v;
+        for (int Jl = 0; Jl < 4; ++Jl) {
+          const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
+          Po[(size_t)(16 * Ig) * MP + oc[Jl]] = v;
+          acc += v;
+        }
+        acc += dpp_f64<0xB1>(acc);      // sum over the four lanes j of the quad (fixed order)
+        acc += dpp_f64<0x4E>(acc);
+        if (jo == 0) rs[16 * Ig] = acc;
       }
-      acc += dpp_f64<0xB1>(acc);      // sum over the four lanes j of the quad (fixed order)
-      acc += dpp_f64<0x4E>(acc);
-      if (jo == 0) rs[16 * Ig] = acc;
-    }
-    __syncthreads();
-    if (w == 0 && lo < MP) {
-      double t = 0.0;
+      __syncthreads();
+      if (w == 0 && lo < MP) {
+        double t = 0.0;
 #pragma unroll
-      for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // fixed order: bit-reproducible
-      a.rowsum[(size_t)gw * MP + lo] = t;
+        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // fixed order: bit-reproducible
+        a.rowsum[(size_t)gw * MP + lo] = t;
+      }
+    } else {
+      // This matrix will be read by ANOTHER workgroup inside this launch (the one that completes the window),
+      // so it is published write-through: |H|^2 goes through LDS (16*G rows at a time) and leaves as whole rows,
+      // 16 bytes per lane, with device-scope (sc1) stores that bypass the non-coherent L2 -- no L2 write-back
+      // (a per-workgroup release fence walks the whole 4 MB L2 and serialises: 36 ms instead of 8.4, measured).
+      constexpr int G = (NT == 3) ? 1 : (NT == 4 ? 2 : NT), TS = MP + 2, C2 = MP / 2, CNT = 16 * G * C2;
+      static_assert(16 * G * TS <= 2 * (L::PBUF + NR * L::NBUF + L::SROW + L::SWAPB), "publish tile overlaps the row sums");
+      double* tile = reinterpret_cast<double*>(smem);
+      // published layout Pp[item][row][f][col]: row-major over frequency (see normalise_row)
+      double* Pg = a.P + (size_t)item * MP * a.F * MP + (size_t)f * MP;
+      static_for<NG / G>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pc)::value;
+        if (pass > 0) __syncthreads();            // the previous pass has been read out
+        static_for<G>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value, Ig = pass * G + g;
+          double acc = 0.0;
+#pragma unroll
+          for (int Jl = 0; Jl < 4; ++Jl) {
+            const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
+            tile[(16 * g + rowo) * TS + oc[Jl]] = v;
+            acc += v;
+          }
+          acc += dpp_f64<0xB1>(acc);
+          acc += dpp_f64<0x4E>(acc);
+          if (jo == 0) rs[16 * Ig] = acc;
+        });
+        __syncthreads();
+#pragma unroll
+        for (int idx = threadIdx.x; idx < CNT; idx += 64 * NT) {
+          const int row = idx / C2, c2 = idx - row * C2;
+          const f64x2 v = *reinterpret_cast<const f64x2*>(tile + row * TS + 2 * c2);
+          store_sc1_b128(Pg + (size_t)(16 * G * pass + row) * a.F * MP + 2 * c2, v);
+        }
+      });
+      if (w == 0 && lo < MP) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // same order as above
+        store_sc1_b64(a.rowsum + (size_t)gw * MP + lo, t);
+      }
     }
   }
 #ifdef HMV_STAMP
@@ -543,6 +731,61 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
     for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
   }
 #endif
+
+  // ---------------------------------------------------------------- fused normalisation (ffDTF)
+  // This workgroup's |H|^2 and row sums were stored write-through (sc1).  Every storing wave drains its stores,
+  // workgroup barrier, then ONE lane counts the matrix on its window (device-scope atomic).  The workgroup whose
+  // count completes the window (agent-scope acquire: its CU's L1 is invalidated) adds up the denominators and
+  // raises ready[window].  Nobody waits for anybody.
+  if constexpr (!GEN) {
+    if (a.ff != nullptr) {                                   // kernel-uniform
+      static_assert(NormLds<NT>::DOUBLES <= 2 * L::TOTAL, "normaliser tiles do not fit the inversion's LDS block");
+      double* nlds = reinterpret_cast<double*>(smem);
+      if (item < a.fuse_items) {                             // workgroup-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const int old = __hip_atomic_fetch_add(a.wcount + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int last = (old == a.F - 1) ? 1 : 0;
+          if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          s_info = last;
+        }
+        __syncthreads();
+        if (s_info != 0) {
+          window_denominators<NT>(a, item, nlds);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (threadIdx.x == 0) __hip_atomic_store(a.ready + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // Rows f, f + F, ... of window item - lag are this workgroup's to normalise.
+      const int wl = item - a.lag;
+      if (wl >= 0 && wl < a.fuse_items && f < a.m) {         // workgroup-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          // No acquire fence here (it costs ~7 us with four workgroups on the CU, 38 000 times per launch): the
+          // flag and the denominator are read with device-scope (sc1) loads, and the |H|^2 rows with non-temporal
+          // loads that bypass this CU's L1 -- every one of those lines was written write-through before ready[wl]
+          // was raised and is read exactly once in the whole launch, so no cache can hold an older copy of it.
+          const int rdy = __hip_atomic_load(a.ready + wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!rdy) {
+            for (int i = f; i < a.m; i += a.F) {
+              const int pos = __hip_atomic_fetch_add(a.missed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              a.missed[1 + pos] = wl * MP + i;
+            }
+          }
+          s_info = rdy;
+        }
+        __syncthreads();
+        if (s_info != 0) {
+          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds);
+        }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- coefficient packing
@@ -596,9 +839,18 @@ long long tf_workspace_doubles(long long n_items, int m_pad, int p) {
   return n_items * (long long)m_pad * m_pad * 2 * ((p + 1) / 2);
 }
 
-int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st) {
+int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
+  TfArgs a = a_in;
+  if (a.n_items == 0 || a.F == 0) return 0;
+  const bool fused = (a.ff != nullptr && a.fuse_items > 0);
+  if (fused) {
+    if (!a.P || !a.den || !a.wcount || !a.ready || !a.missed || a.lag < 1) return -3;
+    // wcount, ready and missed[0] are one zeroed block (capi.hip lays them out back to back)
+    (void)hipMemsetAsync(a.wcount, 0, sizeof(int) * (2 * (size_t)a.n_items + 1), st);
+  } else {
+    a.ff = nullptr;
+  }
   const long long n = a.n_items * (long long)a.F;
-  if (n == 0) return 0;
   const dim3 grid((unsigned)n);
   const long long slots = a.n_items * (long long)m_pad * m_pad * ((a.p + 1) / 2);
   const dim3 pgrid((unsigned)((slots + 255) / 256));
@@ -622,11 +874,23 @@ int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st) {
       break;
     default: return -1;
   }
+  if (fused) {          // rows whose window was not complete in time (normally none)
+    const dim3 mgrid(256);
+    switch (m_pad) {
+      case 16: hipLaunchKernelGGL(norm_missed_kernel<1>, mgrid, dim3(64), 0, st, a); break;
+      case 32: hipLaunchKernelGGL(norm_missed_kernel<2>, mgrid, dim3(128), 0, st, a); break;
+      case 48: hipLaunchKernelGGL(norm_missed_kernel<3>, mgrid, dim3(192), 0, st, a); break;
+      case 64: hipLaunchKernelGGL(norm_missed_kernel<4>, mgrid, dim3(256), 0, st, a); break;
+    }
+  }
   return (int)hipGetLastError();
 }
 
 // general complex inverse of a.Zin (kernel layout), a.H = inverse, a.detph = phase of the determinants
-int launch_cinv(const TfArgs& a, int m_pad, hipStream_t st) {
+int launch_cinv(const TfArgs& a_in, int m_pad, hipStream_t st) {
+  TfArgs a = a_in;
+  a.ff = nullptr;
+  a.fuse_items = 0;
   const long long n = a.n_items * (long long)a.F;
   if (n == 0) return 0;
   const dim3 grid((unsigned)n);

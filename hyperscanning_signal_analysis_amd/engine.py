@@ -214,11 +214,13 @@ class Engine:
 
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
-                      check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True):
+                      check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True,
+                      flags: int = 0):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
         overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the
         chip, then runs as two half-batches that interleave on the device (see include/hypermvar.h).
+        flags: option bits of include/hypermvar.h (`_lib.FLAG_*`); 0 = the fast defaults.
         k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
         have been recorded once) which the library records around the dominant kernel.
         """
@@ -248,7 +250,7 @@ class Engine:
             rc = self.lib.hmv_sliding_ffdtf_f64(
                 x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
                 m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
-                info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau,
+                info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
                 k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
         _lib.check(rc, "hmv_sliding_ffdtf_f64")
         if check:

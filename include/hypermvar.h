@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HMV_VERSION 100            /* 0.1.0 */
+#define HMV_VERSION 110            /* 0.1.1 */
 #define HMV_MAX_CHANNELS 64
 #define HMV_MAX_ORDER 32
 
@@ -114,6 +114,25 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
                            const double* weights, int n_tapers, int64_t bin_lo, int64_t bin_hi, double* psd,
                            void* workspace, int64_t workspace_bytes, int64_t ch_chunk, void* stream);
 
+/* Option bits of the fused entry points (`flags`).  0 = the fast defaults. */
+#define HMV_FLAG_UNFUSED_NORM 1   /* ffDTF normalisation as a separate pass over |H|^2 (K4) instead of inside K3 */
+
+/* K3 + K4 in one pass.  ffdtf[item][i][j][f] = |H_ij(f)|^2 / sum_{j',f'} |H_ij'(f')|^2, i.e. the arithmetic of
+ * mvar_transfer_function (src/mtmvar.py:126-162), |H|^2 (:232) and the normalisation loop of full_freq_dtf
+ * (:281-283).  K3 leaves |H|^2 and its row sums in `workspace` (write-through stores); the workgroup whose
+ * matrix completes a window (device-scope arrival counter) adds up the row denominators, and the rows of that
+ * window are turned into the output array by workgroups of a LATER window of the same launch while the rest of
+ * the chip keeps inverting (nobody waits: a row whose window is not complete in time is done by a small kernel
+ * after K3) -- the separate K4 pass only sees the last few windows of the batch.  Bit-identical to
+ * hmv_tf_f64 + hmv_ffdtf_norm_f64.  Taken when F % 16 == 0 and ffdtf is 16-byte aligned, otherwise K4 does all
+ * windows.  den: [item][MP] out; info: [item*F + f].
+ * ev_k3_start / ev_k3_stop (optional hipEvent_t) are recorded on `stream` around the K3 launch. */
+int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F);
+int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F,
+                     double* ffdtf, double* den, int32_t* info, double pivot_tau,
+                     void* workspace, int64_t workspace_bytes, int64_t flags,
+                     void* ev_k3_start, void* ev_k3_stop, void* stream);
+
 /* Fused sliding-window path K1 -> K2 -> K3 -> K4 over all items, processed `chunk` items at a time so the
  * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].
@@ -133,8 +152,8 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf,
                           void* workspace, int64_t workspace_bytes, int64_t chunk,
-                          double pivot_tau, void* ev_k3_start, void* ev_k3_stop, void* stream,
-                          void* aux_stream);
+                          double pivot_tau, int64_t flags, void* ev_k3_start, void* ev_k3_stop,
+                          void* stream, void* aux_stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,8 @@ def test_header_symbols_all_exported(lib):
     assert sorted(_lib.SIGNATURES) == syms, "ctypes table and include/hypermvar.h disagree"
     for s in syms:
         assert hasattr(lib, s)
-    assert lib.hmv_version() == 100
+    hdr = open(os.path.join(ROOT, "include", "hypermvar.h")).read()
+    assert lib.hmv_version() == int(re.search(r"#define HMV_VERSION (\d+)", hdr).group(1))
 
 
 def test_argument_checks_without_gpu(lib):

@@ -314,6 +314,34 @@ def test_two_stream_overlap_is_bit_identical():
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
 
 
+@pytest.mark.parametrize("m,n,p,F,nw", [(64, 1000, 8, 256, 59), (64, 1000, 8, 48, 75), (4, 160, 5, 32, 500),
+                                          (19, 400, 3, 32, 200), (33, 300, 2, 16, 400), (48, 600, 4, 16, 400),
+                                          (48, 600, 4, 7, 400)])
+def test_normalisation_inside_k3_is_bit_identical_to_separate_pass(m, n, p, F, nw):
+    """ffDTF normalised inside K3 by the workgroup that completes a window (device-scope arrival counter,
+    release / acquire) == |H|^2 written out and normalised by the separate K4 pass, bit for bit, for every
+    window -- the ones inside the batch (fused) and the last few (always left to K4).  (A grid that is not a
+    multiple of 16 frequencies, the last case, is normalised by K4 throughout.)"""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(11, m=m, p=min(p, 4), T=T, burn=300)
+    freqs = np.linspace(0.5, 120.0, F)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    fused = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)
+    again = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)
+    plain = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, flags=_lib.FLAG_UNFUSED_NORM)
+    chunked = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, chunk=max(1, nw // 3 + 1))
+    torch.cuda.synchronize()
+    assert torch.equal(fused, plain) and torch.equal(fused, again) and torch.equal(fused, chunked)
+    assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
+    k = nw // 2
+    assert_parity(fused[k].cpu().numpy(), O.full_freq_dtf(x[:, pos[k]:pos[k] + w], freqs, 500.0, p), 1e-8)
+
+
 def test_multi_dyad_batch_matches_single_dyad_runs():
     """Config 3 in miniature: several dyads in one batch (dyad x window items, forced into several chunks)
     give bit-identical results to running each dyad alone -- the property dyad-sharding across GPUs relies on."""
