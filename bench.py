@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="do not split K2 over two HIP streams")
     ap.add_argument("--unfused-norm", action="store_true",
                     help="ffDTF normalisation as a separate pass (K4) instead of inside K3 (A/B measurements)")
+    ap.add_argument("--yw-one-launch", action="store_true",
+                    help="K2 as one workgroup per window in one launch instead of the chain of tile launches (A/B)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code path "
                          "with several ranks on ONE GPU)")
@@ -120,7 +122,7 @@ def main():
     two_streams = not args.single_stream    # K2 as two half-batches on two HIP streams (library option)
 
     from hyperscanning_signal_analysis_amd import _lib as hlib
-    flags = hlib.FLAG_UNFUSED_NORM if args.unfused_norm else 0
+    flags = (hlib.FLAG_UNFUSED_NORM if args.unfused_norm else 0) | (hlib.FLAG_YW_ONE_LAUNCH if args.yw_one_launch else 0)
 
     def step(k3_events=None):
         eng.sliding_ffdtf(x, item_rec, item_start, w, p, fdev, fs, out=out, check=False,
@@ -177,7 +179,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: 1 dyad/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
                                    "(%d windows), MVAR p=8, 256 freqs 0.5-128 Hz" % (args.minutes, n_windows),
-                       "windows_per_step_per_gpu": n_windows, "k2_streams": 2 if two_streams else 1,
+                       "windows_per_step_per_gpu": n_windows, "k2": "one workgroup per window, one launch" if args.yw_one_launch else "tile launches on %d stream(s)" % (2 if two_streams else 1),
                        "normalisation": "separate K4 pass" if args.unfused_norm else "inside K3 (last arriver)",
                        "parallelism": f"dyad-sharded x{world}",
                        "gather": "band-integrated ffDTF to rank 0 (once, timed)" if world > 1 else "none"},

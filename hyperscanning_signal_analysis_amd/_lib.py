@@ -21,7 +21,7 @@ SIGNATURES = {
     "hmv_lagcov_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                c_void_p, c_void_p]),
     "hmv_yw_solve_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p]),
+                                 c_void_p, c_int64, c_void_p]),
     "hmv_twiddles_f64": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p]),
     "hmv_tf_workspace_doubles": (c_int64, [c_int64, c_int, c_int]),
     "hmv_tf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -49,6 +49,8 @@ SIGNATURES = {
 
 # option bits of the fused entry points (include/hypermvar.h)
 FLAG_UNFUSED_NORM = 1
+FLAG_YW_TILED = 2
+FLAG_YW_ONE_LAUNCH = 4
 
 
 _lib = None

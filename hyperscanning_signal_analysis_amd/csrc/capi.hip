@@ -52,14 +52,14 @@ int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_
 }
 
 int hmv_yw_solve_f64(const double* R, int64_t n_items, int m, int p, double* ws, double* ar, double* V,
-                     double* vq_logdet, int32_t* info, void* stream) {
+                     double* vq_logdet, int32_t* info, int64_t flags, void* stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_yw_solve_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_yw_solve_f64: model order must be in 1..32");
   if (!R || !ws || !ar || !V || !info || n_items < 0) return fail(-4, "hmv_yw_solve_f64: null pointer");
   hmv::YwArgs a;
   a.R = R; a.n_items = n_items; a.m = m; a.p = p; a.ws = ws; a.ar = ar; a.V = V;
-  a.Vq_logdet = vq_logdet; a.info = info;
+  a.Vq_logdet = vq_logdet; a.info = info; a.tiled = (flags & HMV_FLAG_YW_TILED) ? 1 : ((flags & HMV_FLAG_YW_ONE_LAUNCH) ? 0 : -1);
   return hmv::launch_yw(a, mp, S(stream));
 }
 
@@ -311,13 +311,13 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
   const SlidingWs w = sliding_layout(chunk, mp, p, F);
   if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
-  // Second stream: the Yule-Walker stage (K2) is a chain of ~25 launches of at most a few workgroups per
-  // window, two workgroups per CU -- 599 windows need 1.2 "rounds" of the chip per launch and leave most
-  // of it idle.  The windows are independent, so K2 runs as two half-batches, one per stream, whose launches
-  // interleave on the device (fork after K1, join before K3).  Chunk pipelining (K1/K2 of chunk c+1 under K3
-  // of chunk c) was measured and does NOT work: K3 holds every wave slot and starves the other stream.
+  // Second stream (HMV_FLAG_YW_TILED only): the tile-per-workgroup form of K2 is a chain of ~25 launches of at
+  // most a few workgroups per window that cannot fill the chip; it runs as two half-batches, one per stream,
+  // whose launches interleave on the device (fork after K1, join before K3).  The default one-launch form of K2
+  // needs none of this.  Chunk pipelining (K1/K2 of chunk c+1 under K3 of chunk c) was measured and does NOT
+  // work: K3 holds every wave slot and starves the other stream.
   hipStream_t st0 = S(stream), st1 = S(aux_stream);
-  const bool split = (aux_stream && aux_stream != stream);
+  const bool split = (aux_stream && aux_stream != stream) && !(flags & HMV_FLAG_YW_ONE_LAUNCH);
   ForkJoin* fj = nullptr;
   if (split) {
     fj = fork_join_events();
@@ -344,16 +344,20 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     double* V_c = V_out ? V_out + (size_t)i0 * t : V;
     rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, st0);
     if (rc) break;
-    const int64_t c0 = (split && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
+    // the tiled form of K2 (asked for, or chosen for a large 64-channel chunk) as two half-batches
+    const bool tiled = (flags & HMV_FLAG_YW_TILED) || (!(flags & HMV_FLAG_YW_ONE_LAUNCH) && mp == 64 && c >= 128);
+    const int64_t yw_flags = (flags & ~(int64_t)(HMV_FLAG_YW_TILED | HMV_FLAG_YW_ONE_LAUNCH)) |
+                             (tiled ? HMV_FLAG_YW_TILED : HMV_FLAG_YW_ONE_LAUNCH);
+    const int64_t c0 = (split && tiled && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
     if (c1 > 0) {
       (void)hipEventRecord(fj->fork, st0);
       (void)hipStreamWaitEvent(st1, fj->fork, 0);
       rc = hmv_yw_solve_f64(R + (size_t)c0 * (p + 1) * t, c1, m, p, ws + (size_t)c0 * ws_item,
-                            ar_c + (size_t)c0 * t * p, V_c + (size_t)c0 * t, nullptr, info_yw + i0 + c0, st1);
+                            ar_c + (size_t)c0 * t * p, V_c + (size_t)c0 * t, nullptr, info_yw + i0 + c0, yw_flags, st1);
       (void)hipEventRecord(fj->join, st1);
       if (rc) break;
     }
-    rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, st0);
+    rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, yw_flags, st0);
     if (c1 > 0) (void)hipStreamWaitEvent(st0, fj->join, 0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);

@@ -28,6 +28,8 @@ struct YwArgs {
   double* V;                // [n_items][MP][MP]
   double* Vq_logdet;        // optional [n_items][p]: log det V_q for q = 1..p (model-order criterion)
   int* info;                // [n_items]
+  int tiled;                // 0: one workgroup per window, one launch;  1: one workgroup per tile, ~50 launches;
+                            // -1: pick by batch shape (launch_yw)
 };
 long long yw_ws_tiles(int p);
 int launch_yw(const YwArgs& a, int m_pad, hipStream_t st);

@@ -29,6 +29,8 @@
 
 namespace hmv {
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 #define HMV_WAVE_SYNC()                                     \
   do {                                                      \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -405,6 +407,255 @@ __global__ void __launch_bounds__(256) yw_emit_kernel(YwArgs a) {
   }
 }
 
+
+// ---- one workgroup per window: the whole factorisation, back substitution and emit in ONE launch --------------
+// The tile-per-workgroup kernels above need ~50 dependent launches per batch (25 on the critical path), each
+// one round of at most 1.2 workgroups per CU: 2.0 ms for 599 windows, 0.30 of the f64 peak.  Here a workgroup
+// walks the same left-looking schedule for its window on its own -- same tile products in the same order, so
+// the results are bit-identical -- with the scratch tiles in global memory (private to the workgroup: only
+// workgroup barriers order them) and the operands staged through LDS in two k-halves (39 KB, so three
+// workgroups fit a CU and a 599-window batch is resident at once; co-resident workgroups hide each other's
+// staging latency and the serial 64 x 64 inverses).
+template <int NT>
+struct YwWin {
+  static constexpr int MP = 16 * NT, KH = MP / 2, SH = KH + 6, NIW = NT, NJ = NT, TILE = MP * MP;
+  static constexpr int NV = (MP * KH / 2 + 255) / 256;          // 16-byte loads per thread and operand half
+  static constexpr int SI = YwCfg<NT>::S;                        // row stride of the full tile image (inverse)
+  static constexpr int GEMM_D = 2 * MP * SH, INV_D = MP * SI;
+  static constexpr int BUF_D = GEMM_D > INV_D ? GEMM_D : INV_D;  // doubles shared by the two uses
+};
+
+// VQ: also the residual covariances of the lower orders (log det V_q, model-order criterion) -- its own
+// instantiation because the extra tile and inverse do not fit the 168 registers that three workgroups per CU allow.
+template <int NT, bool VQ>
+__global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
+  using W = YwWin<NT>;
+  constexpr int MP = W::MP, KH = W::KH, SH = W::SH, NIW = NT, NJ = NT, TILE = W::TILE, NV = W::NV, SI = W::SI;
+  __shared__ __attribute__((aligned(16))) double buf[W::BUF_D];
+  __shared__ double Pb[MP * 4];
+  __shared__ double Nb[2 * MP * 4];
+  __shared__ int s_info;
+  __shared__ double s_ld[4];
+  double* Xh = buf;                 // [MP][SH]  k-half of the A-operand tile
+  double* Yh = buf + MP * SH;       // [MP][SH]  k-half of the B-operand tile (rows = output columns)
+  const int wv = uni(threadIdx.x >> 6);
+  const long long item = blockIdx.x;
+  const int p = a.p;
+  const YwPtrs q = yw_ptrs<MP>(a, item);
+  if (threadIdx.x == 0) s_info = 0;
+
+  // Lane and thread indices are re-derived from an opaque lane id inside every helper: otherwise the compiler
+  // hoists the (thread-constant) LDS and global offsets of every staging / tile-I/O variant out of the tile loops
+  // and keeps them live across the whole kernel (237 spilled VGPRs at the 168 that three workgroups per CU allow).
+  auto lane = [&]() __attribute__((always_inline)) {
+    int lo;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+    return lo;
+  };
+  auto zero = [&](double (&v)[NIW][NJ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) v[ii][J] = 0.0;
+  };
+  // ---- operand staging, one k-half at a time --------------------------------------------------------------
+  // fetch: the 16-byte loads of a half into registers; park: registers -> LDS.  Plain image: dst[row][k] =
+  // src[row][kh*KH + k]; transposed image: dst[col][k] = src[kh*KH + k][col].
+  auto fetch = [&](f64x2 (&v)[NV], const double* src, int kh, bool tr) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NV * 256 == MP * KH / 2 || idx < MP * KH / 2) {
+        if (!tr) {
+          const int row = idx / (KH / 2), c2 = idx - row * (KH / 2);
+          v[r] = *reinterpret_cast<const f64x2*>(src + (size_t)row * MP + kh * KH + 2 * c2);
+        } else {
+          const int k = idx / (MP / 2), c2 = idx - k * (MP / 2);
+          v[r] = *reinterpret_cast<const f64x2*>(src + (size_t)(kh * KH + k) * MP + 2 * c2);
+        }
+      }
+    }
+  };
+  auto park = [&](double* dst, const f64x2 (&v)[NV], bool tr) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NV * 256 == MP * KH / 2 || idx < MP * KH / 2) {
+        if (!tr) {
+          const int row = idx / (KH / 2), c2 = idx - row * (KH / 2);
+          double* d = dst + row * SH + 2 * c2;
+          d[0] = v[r].x;
+          d[1] = v[r].y;
+        } else {
+          const int k = idx / (MP / 2), c2 = idx - k * (MP / 2);
+          dst[(2 * c2) * SH + k] = v[r].x;
+          dst[(2 * c2 + 1) * SH + k] = v[r].y;
+        }
+      }
+    }
+  };
+  // this wave's row strip of a register tile -> the A-operand half (columns kh*KH .. of the tile)
+  auto park_strip = [&](const double (&v)[NIW][NJ], int kh) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int col = 16 * J + cc - kh * KH;
+        if (col >= 0 && col < KH) Xh[(4 * (wv * NT + ii) + i) * SH + col] = v[ii][J];
+      }
+  };
+  // acc += Xh(rows of this wave) * Yh^T over the staged k-half
+  auto gemm_half = [&](double (&acc)[NIW][NJ]) __attribute__((always_inline)) {
+    const int l = lane();
+    const double* xa = Xh + (4 * wv * NT + (l & 3)) * SH + (l >> 4);
+    const double* yb = Yh + (l & 15) * SH + (l >> 4);
+#pragma unroll 2
+    for (int k0 = 0; k0 < KH; k0 += 4) {
+      double av[NIW], bv[NJ];
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * SH + k0];
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * SH + k0];
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[ii], bv[J], acc[ii][J]);
+    }
+  };
+  // acc += X * Y'^T with X = srcX (global tile) or, if srcX == nullptr, the register tile xr of this workgroup;
+  // Y' = srcY, transposed if trY.  k runs 0 .. MP-1 in ascending order, as in the tile kernels (same bits).
+  // The loads of the second half are in flight behind the MFMAs of the first.
+  auto product = [&](double (&acc)[NIW][NJ], const double* srcX, const double (&xr)[NIW][NJ], const double* srcY,
+                     bool trY) __attribute__((always_inline)) {
+    f64x2 vx[NV], vy[NV];
+    if (srcX) fetch(vx, srcX, 0, false);
+    fetch(vy, srcY, 0, trY);
+    __syncthreads();                          // the previous product has finished reading Xh / Yh
+    if (srcX) park(Xh, vx, false); else park_strip(xr, 0);
+    park(Yh, vy, trY);
+    if (srcX) fetch(vx, srcX, 1, false);
+    fetch(vy, srcY, 1, trY);
+    __syncthreads();
+    gemm_half(acc);
+    __syncthreads();
+    if (srcX) park(Xh, vx, false); else park_strip(xr, 1);
+    park(Yh, vy, trY);
+    __syncthreads();
+    gemm_half(acc);
+  };
+  auto load_G = [&](double (&g)[NIW][NJ], int ta, int tb) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+    // tile (ta, tb) of the augmented matrix straight from the lag covariances: R_{ta-tb}, R_{tb+1}^T or R_0
+    const bool tr = !(ta < p) && (tb < p);
+    const double* src = q.R + (size_t)((ta < p) ? (ta - tb) : (tb < p ? tb + 1 : 0)) * TILE;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int row = 4 * (wv * NT + ii) + i, col = 16 * J + cc;
+        g[ii][J] = tr ? src[col * MP + row] : src[row * MP + col];
+      }
+  };
+  auto store_tile = [&](double* dst, const double (&v)[NIW][NJ]) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) dst[(size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc] = v[ii][J];
+  };
+  auto load_tile = [&](double (&v)[NIW][NJ], const double* src) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) v[ii][J] = src[(size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc];
+  };
+  // full tile image for the cooperative inverse (aliases the operand halves)
+  auto tile_to_lds = [&](const double (&v)[NIW][NJ]) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) buf[(4 * (wv * NT + ii) + i) * SI + 16 * J + cc] = v[ii][J];
+    __syncthreads();
+  };
+
+  double g[NIW][NJ], acc[NIW][NJ];
+  const double (&none)[NIW][NJ] = g;
+  for (int tb = 0; tb <= p; ++tb) {
+    // ---- diagonal tile: D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ; D^-1 (tb < p) or V (tb == p)
+    load_G(g, tb, tb);
+    zero(acc);
+    for (int c = 0; c < tb; ++c) {
+      product(acc, q.Lt + yw_tri(tb, c) * TILE, none, q.Yt + yw_tri(tb, c) * TILE, false);
+      if (VQ && tb == p) {   // V_{c+1}: residual covariance of order c+1 (model-order criterion)
+        double vq[NIW][NJ];
+#pragma unroll
+        for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) vq[ii][J] = g[ii][J] - acc[ii][J];
+        tile_to_lds(vq);
+        spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, nullptr, a.Vq_logdet + (size_t)item * p + c, tb * MP);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+    if (tb == p) {
+      store_tile(a.V + (size_t)item * TILE, g);
+      break;
+    }
+    tile_to_lds(g);
+    spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
+    __syncthreads();                   // D^-1 is in global memory for the whole workgroup
+    // ---- tiles below it: Y = G - sum_c Lt[ta][c] Y[tb][c]^T ; Lt = Y D^-1
+    for (int ta = tb + 1; ta <= p; ++ta) {
+      load_G(g, ta, tb);
+      zero(acc);
+      for (int c = 0; c < tb; ++c)
+        product(acc, q.Lt + yw_tri(ta, c) * TILE, none, q.Yt + yw_tri(tb, c) * TILE, false);
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+      store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
+      zero(acc);
+      product(acc, nullptr, g, q.Dinv + (size_t)tb * TILE, true);
+      store_tile(q.Lt + yw_tri(ta, tb) * TILE, acc);
+      if (ta == p) store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
+    }
+    __syncthreads();                   // column tb of Y / Lt is complete before column tb + 1 reads it
+  }
+  if (threadIdx.x == 0 && s_info != 0) a.info[item] = s_info;
+  // ---- back substitution with the unit lower factor: Z[b] -= Z[c] Lt[c][b] for b < c, c = p-1 .. 1
+  __syncthreads();
+  for (int c = p - 1; c >= 1; --c) {
+    for (int b = 0; b < c; ++b) {
+      load_tile(g, q.Zt + (size_t)b * TILE);
+      zero(acc);
+      product(acc, q.Zt + (size_t)c * TILE, none, q.Lt + yw_tri(c, b) * TILE, true);
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+      store_tile(q.Zt + (size_t)b * TILE, g);
+    }
+    __syncthreads();                   // Z[0 .. c-1] of this round before the next pivot block reads Z[c-1]
+  }
+  // ---- ar[item][row][col][k] = Z[k][row][col]  (lag fastest: the reference's (m, m, p) layout)
+  double* ar = a.ar + (size_t)item * TILE * p;
+  const int total = TILE * p;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int e = idx / p, k = idx - e * p;
+    ar[idx] = q.Zt[(size_t)k * TILE + e];
+  }
+}
+
 template <int NT>
 static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   const int p = a.p;
@@ -421,6 +672,28 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
 
 int launch_yw(const YwArgs& a, int m_pad, hipStream_t st) {
   if (a.n_items == 0) return 0;
+  // One launch per batch is the low-latency form (small batches, small tiles).  At 64 channels and hundreds of
+  // windows both forms are bound by the same HBM traffic (~14 MB of tile operands per window, far more than any
+  // cache holds for a resident batch) and the launch chain, whose every launch streams with the whole chip, is the
+  // faster one: 2.0 ms against 2.26 ms for 599 windows (profiles/r02_ab_notes.md).
+  const bool one_launch = a.tiled == 0 || (a.tiled < 0 && !(m_pad == 64 && a.n_items >= 128));
+  if (one_launch) {
+    (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
+    const dim3 grid((unsigned)a.n_items), block(256);
+    const bool vq = (a.Vq_logdet != nullptr);
+    switch (m_pad) {
+      case 16: if (vq) hipLaunchKernelGGL((yw_window_kernel<1, true>), grid, block, 0, st, a);
+               else hipLaunchKernelGGL((yw_window_kernel<1, false>), grid, block, 0, st, a); break;
+      case 32: if (vq) hipLaunchKernelGGL((yw_window_kernel<2, true>), grid, block, 0, st, a);
+               else hipLaunchKernelGGL((yw_window_kernel<2, false>), grid, block, 0, st, a); break;
+      case 48: if (vq) hipLaunchKernelGGL((yw_window_kernel<3, true>), grid, block, 0, st, a);
+               else hipLaunchKernelGGL((yw_window_kernel<3, false>), grid, block, 0, st, a); break;
+      case 64: if (vq) hipLaunchKernelGGL((yw_window_kernel<4, true>), grid, block, 0, st, a);
+               else hipLaunchKernelGGL((yw_window_kernel<4, false>), grid, block, 0, st, a); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   switch (m_pad) {
     case 16: return launch_yw_nt<1>(a, st);
     case 32: return launch_yw_nt<2>(a, st);

@@ -86,7 +86,7 @@ class Engine:
         return R
 
     # ------------------------------------------------------------------ K2
-    def yw_solve(self, R: torch.Tensor, m: int, want_logdet: bool = False):
+    def yw_solve(self, R: torch.Tensor, m: int, want_logdet: bool = False, flags: int = 0):
         n_items, p1, mp, _ = R.shape
         p = p1 - 1
         ws = self.empty(n_items * int(self.lib.hmv_yw_workspace_doubles(m, p)))
@@ -96,7 +96,7 @@ class Engine:
         logdet = self.empty(n_items, p) if want_logdet else None
         with torch.cuda.device(self.device):
             rc = self.lib.hmv_yw_solve_f64(R.data_ptr(), n_items, m, p, ws.data_ptr(), ar.data_ptr(), V.data_ptr(),
-                                           _ptr(logdet), info.data_ptr(), self.stream())
+                                           _ptr(logdet), info.data_ptr(), int(flags), self.stream())
         _lib.check(rc, "hmv_yw_solve_f64")
         return ar, V, logdet, info
 

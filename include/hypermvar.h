@@ -51,9 +51,10 @@ int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld,
  * ar: [item][MP][MP][p] with ar[i][j][k] multiplying x_j(t-k-1) into x_i(t) (lag fastest: the
  * reference's own (m, m, p) layout when m == MP); V: [item][MP][MP] residual covariance.
  * vq_logdet (optional, may be NULL): [item][p] = log det V_q for model orders q = 1..p, all from the one
- * factorisation at order p (what mvar_criterion, src/mtmvar.py:551-601, gets from p separate fits). */
+ * factorisation at order p (what mvar_criterion, src/mtmvar.py:551-601, gets from p separate fits).
+ * flags: 0, HMV_FLAG_YW_TILED or HMV_FLAG_YW_ONE_LAUNCH (below). */
 int hmv_yw_solve_f64(const double* R, int64_t n_items, int m, int p, double* ws,
-                     double* ar, double* V, double* vq_logdet, int32_t* info, void* stream);
+                     double* ar, double* V, double* vq_logdet, int32_t* info, int64_t flags, void* stream);
 
 /* tw[f][k] = exp(-(k+1) * 2*pi*1j * freqs[f] / fs) as interleaved (re, im), k = 0..p-1
  * (src/mtmvar.py:151-153, same operation order). */
@@ -116,6 +117,10 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
 
 /* Option bits of the fused entry points (`flags`).  0 = the fast defaults. */
 #define HMV_FLAG_UNFUSED_NORM 1   /* ffDTF normalisation as a separate pass over |H|^2 (K4) instead of inside K3 */
+#define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in ~50 launches, and                          */
+#define HMV_FLAG_YW_ONE_LAUNCH 4  /* K2 as one workgroup per window in one launch: same tile products in the same
+                                     order, same bits.  Neither flag: one launch, except for large 64-channel
+                                     batches, where both forms are HBM-bound and the launch chain is faster. */
 
 /* K3 + K4 in one pass.  ffdtf[item][i][j][f] = |H_ij(f)|^2 / sum_{j',f'} |H_ij'(f')|^2, i.e. the arithmetic of
  * mvar_transfer_function (src/mtmvar.py:126-162), |H|^2 (:232) and the normalisation loop of full_freq_dtf
@@ -141,8 +146,8 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
  * ev_k3_start / ev_k3_stop (optional hipEvent_t, NULL to skip) are recorded on `stream` right before
  * and after the LAST chunk's K3 launch, so a caller can time the dominant kernel inside its own timed
  * region without an extra synchronisation.
- * aux_stream (optional second hipStream_t, NULL to disable): the Yule-Walker stage K2 -- ~25 launches of a
- * few workgroups per window that cannot fill the chip -- runs as two half-batches, one per stream (fork
+ * aux_stream (optional second hipStream_t, NULL to disable; used by the tiled form of K2 only): ~25 dependent
+ * launches that cannot fill the chip -- it runs as two half-batches, one per stream (fork
  * after K1, join before K3), so their launches interleave on the device; the call still behaves as one
  * operation on `stream`. */
 int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F);

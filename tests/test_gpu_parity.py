@@ -306,12 +306,15 @@ def test_two_stream_overlap_is_bit_identical():
     from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
     pos, w = window_positions(12_000, 23, 1000)
     rec, st = window_items(1, pos, eng.device)
-    a = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=False)
-    b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=True)     # 12 + 11 windows
-    c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False)
-    d = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=17, overlap=True)     # 9 + 8, then 6 unsplit
+    from hyperscanning_signal_analysis_amd import _lib
+    T = _lib.FLAG_YW_TILED          # the launch-chain form of K2 (the one that is split over the two streams)
+    a = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=False, flags=T)
+    b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=True, flags=T)     # 12 + 11 windows
+    c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False, flags=T)
+    d = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=17, overlap=True, flags=T)     # 9 + 8, then 6 unsplit
+    e = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23)                   # default: K2 in one launch
     torch.cuda.synchronize()
-    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(a, e)
 
 
 @pytest.mark.parametrize("m,n,p,F,nw", [(64, 1000, 8, 256, 59), (64, 1000, 8, 48, 75), (4, 160, 5, 32, 500),
@@ -340,6 +343,31 @@ def test_normalisation_inside_k3_is_bit_identical_to_separate_pass(m, n, p, F, n
     assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
     k = nw // 2
     assert_parity(fused[k].cpu().numpy(), O.full_freq_dtf(x[:, pos[k]:pos[k] + w], freqs, 500.0, p), 1e-8)
+
+
+@pytest.mark.parametrize("m,n,p", [(64, 1000, 8), (64, 700, 3), (50, 900, 5), (33, 500, 2), (19, 400, 6), (16, 300, 1),
+                                   (5, 200, 9)])
+def test_yule_walker_one_launch_equals_tiled_launch_chain(m, n, p):
+    """K2 as one workgroup per window (one launch, operands staged in k-halves) walks the same tile products in
+    the same order as the round-1 chain of ~50 tile launches: coefficients, residual covariance and the log
+    determinants of the lower orders are the same bits; and both agree with the oracle."""
+    from hyperscanning_signal_analysis_amd import _lib
+    eng = default_engine()
+    W = 37
+    x = synthetic_var_dyad(21, m=m, p=min(p, 4), T=n + 10 * (W - 1), burn=300)
+    xd = eng.to_device(x[None])
+    rec = torch.zeros(W, dtype=torch.int64, device=eng.device)
+    st = 10 * torch.arange(W, dtype=torch.int64, device=eng.device)
+    R = eng.lagcov(xd, rec, st, n, p)
+    for want_logdet in (False, True):
+        a1, v1, l1, i1 = eng.yw_solve(R, m, want_logdet, flags=_lib.FLAG_YW_ONE_LAUNCH)
+        a2, v2, l2, i2 = eng.yw_solve(R, m, want_logdet, flags=_lib.FLAG_YW_TILED)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2) and torch.equal(v1, v2) and not bool(i1.any()) and not bool(i2.any())
+        if want_logdet:
+            assert torch.equal(l1, l2)
+    aro, Vo = O.ar_coeff(x[:, 50:50 + n], p)
+    assert_parity(a1[5, :m, :m].cpu().numpy(), aro, 1e-8); assert_parity(v1[5, :m, :m].cpu().numpy(), Vo, 1e-8)
 
 
 def test_multi_dyad_batch_matches_single_dyad_runs():
