@@ -4,10 +4,13 @@
 Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "C2"): per GPU ONE synthetic dyad,
 2 x 32 channels @ 500 Hz, 10 minutes (T = 300 000), 2 s windows with 50 % overlap (599 windows),
 MVAR order p = 8, 256-point frequency grid 0.5 .. 128 Hz, float64.  One "step" = one pass of the hot path
-(K1 lag covariance -> K2 Yule-Walker -> K3 transfer inverse + |H|^2 -> K4 ffDTF normalisation) over
-those 599 windows, input already resident in HBM, output left in HBM as (599, 64, 64, 256) float64.
-N > 1: weak scaling, rank r processes dyad r (no data-path collective); after the K timed steps ONE
-RCCL gather of the band-integrated ffDTF to rank 0 (inside the timed region).
+(K1 lag covariance -> K2 Yule-Walker -> K3 transfer inverse + |H|^2 + ffDTF normalisation; K4 only for the
+last windows of the batch) over those windows, input already resident in HBM, output left in HBM as
+(windows, 64, 64, 256) float64.
+`--dyads-per-gpu D` puts D dyads on every GPU (D x 599 windows per step, processed in chunks of one dyad);
+`--gpus 8 --dyads-per-gpu 8` is BASELINE.json configs[2] ("C3": 64 dyads, dyad-sharded across 8 GPUs).
+N > 1: weak scaling, rank r processes dyads r*D .. r*D+D-1 (no data-path collective); after the K timed steps
+ONE RCCL gather of the band-integrated ffDTF to rank 0 (inside the timed region).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -16,7 +19,11 @@ RCCL gather of the band-integrated ffDTF to rank 0 (inside the timed region).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
 kernel (K3, timed with HIP events recorded by the library around its launch inside the timed region)
 and `cpu_baseline` (the NumPy port of the reference's loop structure, oracle/mvar_oracle.py, on a
-bounded sample of the same windows, rank 0 only).
+bounded sample of the same windows, rank 0 only; the vectorised restatement and an all-cores run are
+reported as sub-fields).  The timed steps run with check=False (the singularity check is a device
+synchronisation, not work); after the timed region one extra step is checked: both info arrays zero, every
+ffDTF row sums to one, the in-kernel normalisation equals the separate K4 pass bit for bit on the whole
+output, and one window equals the oracle.
 """
 import argparse
 import json
@@ -30,6 +37,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from hyperscanning_signal_analysis_amd import _lib as hlib                  # noqa: E402
 from hyperscanning_signal_analysis_amd import distributed as hdist          # noqa: E402
 from hyperscanning_signal_analysis_amd.engine import Engine                 # noqa: E402
 from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions  # noqa: E402
@@ -46,26 +54,47 @@ FLOP_K3_WINDOW = FLOP_AF + FLOP_INV + 3.0 * 64 * 64 * 256                    # 5
 PEAK_F64_TFLOPS = 78.6          # MI355X spec, vector = matrix f64 (measured ceiling ~65: DESIGN.md)
 
 
-def cpu_baseline(x_host, positions, w, p, freqs, fs, budget_s=15.0, max_windows=256):
-    """Reference-style (per-frequency Python loop) NumPy port timed on this host, 1 BLAS thread."""
+def cpu_baseline(x_host, positions, w, p, freqs, fs, budget_s=12.0, max_windows=256):
+    """CPU numbers beside the GPU one, all on bounded samples of dyad 0's windows:
+    value      the reference-style port (per-frequency Python loop, per-(i,j) normalisation loop), 1 BLAS thread;
+    vectorised the same math with batched LAPACK calls, 1 process / 1 BLAS thread;
+    all_cores  the vectorised restatement in one process per core (multiprocessing), 1 BLAS thread each."""
     from oracle import mvar_oracle as O      # the ONLY place bench.py touches oracle/
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:                         # pragma: no cover
-        import contextlib
-        ctx = contextlib.nullcontext()
-    done, t0 = 0, time.perf_counter()
-    with ctx:
-        for s in positions[:max_windows]:
-            O.full_freq_dtf_loop(x_host[:, s:s + w], freqs, fs, p)
-            done += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "windows/s", "cores": 1, "kind": "port",
-            "sample": f"first {done} of the {len(positions)} windows of dyad 0, oracle.full_freq_dtf_loop "
-                      f"(reference loop structure, NumPy/OpenBLAS 1 thread), {dt:.1f} s"}
+    from threadpoolctl import threadpool_limits
+    out = {}
+    with threadpool_limits(limits=1):
+        for key, fn, budget in (("loop", O.full_freq_dtf_loop, budget_s), ("vec", O.full_freq_dtf, budget_s / 3)):
+            done, t0 = 0, time.perf_counter()
+            for s in positions[:max_windows]:
+                fn(x_host[:, s:s + w], freqs, fs, p)
+                done += 1
+                if time.perf_counter() - t0 > budget:
+                    break
+            out[key] = (done, time.perf_counter() - t0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(cores, 16))            # the GPU box gives one GPU's job a 16-core share
+    allc = None
+    try:                                      # a CHILD process (NumPy + oracle only, forks its own workers)
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "x.npy")
+            np.save(path, np.ascontiguousarray(x_host[:, :min(x_host.shape[1], 64 * w)]))
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_allcores.py"), path, str(w),
+                                str(int(positions[1] - positions[0]) if len(positions) > 1 else w), str(p),
+                                str(len(freqs)), str(fs), str(procs), str(budget_s / 2)],
+                               capture_output=True, text=True, timeout=120)
+        allc = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                    # pragma: no cover  (never let the side measurement kill the bench)
+        allc = {"error": repr(e)}
+    d, dt = out["loop"]
+    dv, dtv = out["vec"]
+    return {"value": d / dt, "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"first {d} of the {len(positions)} windows of dyad 0, oracle.full_freq_dtf_loop "
+                      f"(reference loop structure, NumPy/OpenBLAS 1 thread), {dt:.1f} s",
+            "vectorised": {"value": dv / dtv, "unit": "windows/s", "cores": 1, "blas_threads": 1,
+                           "sample": f"first {dv} windows, oracle.full_freq_dtf (batched LAPACK), {dtv:.1f} s"},
+            "all_cores": allc, "host_cores_visible": cores}
 
 
 def main():
@@ -75,7 +104,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--minutes", type=float, default=10.0, help="recording length per dyad (default 10)")
-    ap.add_argument("--single-stream", action="store_true", help="do not split K2 over two HIP streams")
+    ap.add_argument("--dyads-per-gpu", type=int, default=1,
+                    help="dyads per GPU (8 with --gpus 8 = BASELINE config 3: 64 dyads); one chunk per dyad")
+    ap.add_argument("--single-stream", action="store_true", help="do not give the library its second HIP stream")
     ap.add_argument("--unfused-norm", action="store_true",
                     help="ffDTF normalisation as a separate pass (K4) instead of inside K3 (A/B measurements)")
     ap.add_argument("--yw-one-launch", action="store_true",
@@ -90,14 +121,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     rehearsal = (args.backend == "gloo")                 # every rank on GPU 0, host-side collectives
-    dev = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1:                                         # rendezvous BEFORE anything touches the GPU
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1 and not rehearsal:
+        dist.init_process_group("nccl", device_id=dev)
 
     ns = NORTHSTAR
     m, fs, w, p, F = ns["m"], ns["fs"], ns["window"], ns["p"], ns["F"]
@@ -105,28 +136,30 @@ def main():
     n_windows = 2 * T // w - 1
     positions, w = window_positions(T, n_windows, w)
     freqs = northstar_freqs(F)
+    D = max(1, args.dyads_per_gpu)
 
-    x_host = synthetic_var_dyad(rank, m=m, p=p, T=T, fs=fs)           # weak scaling: dyad index = rank
+    # weak scaling: dyad index = rank * D + d
+    x_hosts = [synthetic_var_dyad(rank * D + d, m=m, p=p, T=T, fs=fs) for d in range(D)]
     eng = Engine(device=dev, max_workspace_bytes=64 << 30)
-    x = eng.to_device(x_host[None])                                     # (1, 64, T) resident in HBM
-    item_rec, item_start = window_items(1, positions, dev)
+    x = eng.to_device(np.stack(x_hosts))                                # (D, 64, T) resident in HBM
+    item_rec, item_start = window_items(D, positions, dev)
     fdev = eng.to_device(freqs)
-    out = eng.empty(n_windows, m, m, F)
+    n_items = D * n_windows
+    out = eng.empty(n_items, m, m, F)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:                                                     # create the hipEvent_t handles
         a.record(); b.record()
     torch.cuda.synchronize()
 
-    chunk = n_windows                       # one chunk per step: K1, K3, K4 are launched once per step
-    k3_windows = n_windows                  # windows of the K3 launch the events bracket
-    two_streams = not args.single_stream    # K2 as two half-batches on two HIP streams (library option)
-
-    from hyperscanning_signal_analysis_amd import _lib as hlib
+    chunk = n_windows                       # one chunk per dyad: K1, K3 are launched once per dyad and step
+    k3_windows = n_windows                  # windows of the K3 launch the events bracket (the last chunk's)
+    two_streams = not args.single_stream
     flags = (hlib.FLAG_UNFUSED_NORM if args.unfused_norm else 0) | (hlib.FLAG_YW_ONE_LAUNCH if args.yw_one_launch else 0)
 
-    def step(k3_events=None):
-        eng.sliding_ffdtf(x, item_rec, item_start, w, p, fdev, fs, out=out, check=False,
-                          chunk=chunk, k3_events=k3_events, overlap=two_streams, flags=flags)
+    def step(k3_events=None, check=False, dst=None, fl=None):
+        return eng.sliding_ffdtf(x, item_rec, item_start, w, p, fdev, fs, out=out if dst is None else dst, check=check,
+                                 chunk=chunk, k3_events=k3_events, overlap=two_streams,
+                                 flags=flags if fl is None else fl, return_ar=check)
 
     def barrier():
         if world > 1:
@@ -144,7 +177,7 @@ def main():
     for k in range(args.steps):
         step((ev[k][0].cuda_event, ev[k][1].cuda_event))
     if world > 1:                                                       # the single gather at the end
-        bands = hdist.band_integrate(out, freqs)
+        bands = hdist.band_integrate(out, freqs, engine=eng)
         gathered = hdist.gather_to_root(bands.cpu() if rehearsal else bands, dst=0)
     torch.cuda.synchronize()
     barrier()
@@ -154,22 +187,42 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if rank == 0:
+            assert gathered.shape[0] == world and bool(torch.isfinite(gathered).all())
 
-    # sanity inside the bench: rows of every window sum to one, nothing singular
-    rowsum_err = float((out.sum(dim=(2, 3)) - 1.0).abs().max().item())
-    if not os.environ.get("HYPERMVAR_BENCH_NOCHECK"):          # diagnostic kernel variants only
+    # ---- after the timed region: one checked step (diagnostic kernel variants may skip it)
+    checks = {}
+    if not os.environ.get("HYPERMVAR_BENCH_NOCHECK"):
+        _, _, _, (info_yw, info_tf) = step(check=True)                 # raises on any singular window
+        checks["info_all_zero"] = not (bool(info_yw.any()) or bool(info_tf.any()))
+        rowsum_err = float((out.sum(dim=(2, 3)) - 1.0).abs().max().item())
         assert rowsum_err < 1e-9, f"ffDTF rows do not sum to 1 ({rowsum_err})"
+        checks["max_row_sum_error"] = rowsum_err
+        other = eng.empty(n_windows, m, m, F)                           # the other normalisation path, dyad 0
+        eng.sliding_ffdtf(x[:1], item_rec[:n_windows], item_start[:n_windows], w, p, fdev, fs, out=other, check=False,
+                          chunk=chunk, overlap=two_streams, flags=flags ^ hlib.FLAG_UNFUSED_NORM)
+        checks["fused_equals_separate_normalisation_bitwise"] = bool(torch.equal(other, out[:n_windows]))
+        assert checks["fused_equals_separate_normalisation_bitwise"], "in-kernel and separate normalisation differ"
+        del other
+        if rank == 0:
+            from oracle import mvar_oracle as O                          # checker only
+            kw = n_windows // 2
+            ref = O.full_freq_dtf(x_hosts[0][:, positions[kw]:positions[kw] + w], freqs, fs, p)
+            got = out[kw].cpu().numpy()
+            checks["oracle_window_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            assert checks["oracle_window_rel_err"] < 1e-9
 
     if rank == 0:
         k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        windows_total = world * n_windows * args.steps
+        windows_total = world * n_items * args.steps
         value = windows_total / dt
         achieved = FLOP_K3_WINDOW * k3_windows / (k3_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "k3_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                tj = json.load(open(pmc))
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/k3_traffic.json (%s)" % tj.get("round", "r01")
             except Exception:
                 traffic = None
         res = {
@@ -177,21 +230,29 @@ def main():
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: 1 dyad/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
-                                   "(%d windows), MVAR p=8, 256 freqs 0.5-128 Hz" % (args.minutes, n_windows),
-                       "windows_per_step_per_gpu": n_windows, "k2": "one workgroup per window, one launch" if args.yw_one_launch else "tile launches on %d stream(s)" % (2 if two_streams else 1),
-                       "normalisation": "separate K4 pass" if args.unfused_norm else "inside K3 (last arriver)",
+            "config": {"workload": "C%d: %d dyad(s)/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
+                                   "(%d windows per dyad), MVAR p=8, 256 freqs 0.5-128 Hz"
+                                   % (2 if D == 1 else 3, D, args.minutes, n_windows),
+                       "windows_per_step_per_gpu": n_items, "dyads_per_gpu": D,
+                       "k2": "one workgroup per window, one launch" if args.yw_one_launch
+                             else "tile launches on %d stream(s)" % (2 if two_streams else 1),
+                       "normalisation": "separate K4 pass" if args.unfused_norm else "inside K3 (rows of window w by "
+                                        "workgroups of window w+lag)",
+                       "timed_steps_check_singularity": False,
                        "parallelism": f"dyad-sharded x{world}",
                        "gather": "band-integrated ffDTF to rank 0 (once, timed)" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4, false> (K3)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4, false> (K3%s)"
+                                  % ("" if args.unfused_norm else ", incl. the in-kernel ffDTF normalisation"),
+                         "achieved": achieved,
                          "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
-                         "traffic": traffic, "k3_ms_per_launch": k3_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "k3_ms_per_launch": k3_ms,
                          "flop_per_launch": FLOP_K3_WINDOW * k3_windows, "windows_per_launch": k3_windows},
             "path_tflops": FLOP_WINDOW * value / world / 1e12,
             "path_frac_of_peak": FLOP_WINDOW * value / world / 1e12 / PEAK_F64_TFLOPS,
+            "checks_after_timed_region": checks,
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(x_host, positions, w, p, freqs, fs)
+            res["cpu_baseline"] = cpu_baseline(x_hosts[0], positions, w, p, freqs, fs)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res))

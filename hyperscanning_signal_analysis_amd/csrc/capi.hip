@@ -156,6 +156,26 @@ int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, i
   return hmv::launch_gpdc(A, V, G, n_items, F, m, mp, S(stream));
 }
 
+int hmv_trial_mean_f64(const double* R_trials, int64_t n_trials, int m, int p, double* R_mean, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_trial_mean_f64: channel count must be in 1..64");
+  if (!R_trials || !R_mean || n_trials < 1 || n_trials > 0x7fffffff || p < 0)
+    return fail(-4, "hmv_trial_mean_f64: bad argument");
+  return hmv::launch_trial_mean(R_trials, R_mean, (long long)(p + 1) * mp * mp, (int)n_trials, S(stream));
+}
+
+int hmv_ddtf_f64(const double* ffdtf, const double* kappa, double* ddtf, int64_t n_items, int m, int F, void* stream) {
+  if (!ffdtf || !kappa || !ddtf || n_items < 0 || m < 1 || F < 0) return fail(-4, "hmv_ddtf_f64: bad argument");
+  return hmv::launch_ddtf(ffdtf, kappa, ddtf, (long long)n_items * m * m * F, S(stream));
+}
+
+int hmv_band_sums_f64(const double* ffdtf, int64_t n_rows, int F, const int32_t* bin_lo, const int32_t* bin_hi,
+                      int n_bands, double* out, void* stream) {
+  if (!ffdtf || !bin_lo || !bin_hi || !out || n_rows < 0 || F < 1 || n_bands < 0)
+    return fail(-4, "hmv_band_sums_f64: bad argument");
+  return hmv::launch_band_sums(ffdtf, bin_lo, bin_hi, out, n_rows, F, n_bands, S(stream));
+}
+
 int64_t hmv_psd_workspace_bytes(int64_t ch_chunk, int64_t n_times, int n_tapers) {
   if (ch_chunk < 1 || n_times < 2 || n_tapers < 1) return -1;
   return (int64_t)hmv::psd_workspace_bytes(ch_chunk, n_times, n_tapers);

@@ -108,6 +108,59 @@ __global__ void __launch_bounds__(256) transpose_c128_kernel(const double2* in, 
   }
 }
 
+// ---- small elementwise companions of the path (nothing of this arithmetic is left to the host framework) -----
+// out[e] = (in[0][e] + in[1][e] + ... + in[T-1][e]) / T : the trial average of count_corr
+// (/root/reference/src/mtmvar.py:78-85: the totals are accumulated trial by trial, then divided by `trials`).
+__global__ void __launch_bounds__(256) trial_mean_kernel(const double* in, double* out, long long n, int trials) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  double acc = 0.0;
+  for (int t = 0; t < trials; ++t) acc = acc + in[(size_t)t * n + e];
+  out[e] = (trials > 1) ? acc / (double)trials : acc;
+}
+// dDTF = ffDTF * |partial coherence| (mtmvar.py:341-385, `ff_dtf * np.abs(kappa)`), both (items, m, m, F).
+__global__ void __launch_bounds__(256) ddtf_kernel(const double* ff, const double2* kappa, double* out, long long n) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const double2 k = kappa[e];
+  out[e] = ff[e] * hypot(k.x, k.y);
+}
+// out[r][b] = sum of in[r][f] over the bins lo[b] <= f < hi[b], r = one (item, i, j) row of an (items, m, m, F)
+// array, ascending f (the band-integrated product that is gathered across GPUs; the reference's graph plots sum
+// ffDTF over a frequency range the same way, mtmvar.py:984-987).  One wave per row, 4 rows per workgroup.
+__global__ void __launch_bounds__(256) band_sums_kernel(const double* in, const int* lo, const int* hi, double* out,
+                                                        long long rows, int F, int nb) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int l = threadIdx.x & 63;
+  const double* src = in + (size_t)r * F;
+  for (int b = 0; b < nb; ++b) {
+    double acc = 0.0;
+    for (int f = lo[b] + l; f < hi[b]; f += 64) acc += src[f];      // lane partial sums, ascending f
+    acc = row16_sum_dpp(acc);                                       // fixed-order tree over the 64 lanes
+    const double t = ((readlane_f64(acc, 0) + readlane_f64(acc, 16)) + readlane_f64(acc, 32)) + readlane_f64(acc, 48);
+    if (l == 0) out[(size_t)r * nb + b] = t;
+  }
+}
+
+int launch_trial_mean(const double* in, double* out, long long n, int trials, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(trial_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, trials);
+  return (int)hipGetLastError();
+}
+int launch_ddtf(const double* ff, const double* kappa, double* out, long long n, hipStream_t st) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ddtf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ff,
+                     reinterpret_cast<const double2*>(kappa), out, n);
+  return (int)hipGetLastError();
+}
+int launch_band_sums(const double* in, const int* lo, const int* hi, double* out, long long rows, int F, int nb,
+                     hipStream_t st) {
+  if (rows == 0 || nb == 0) return 0;
+  hipLaunchKernelGGL(band_sums_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, lo, hi, out, rows, F, nb);
+  return (int)hipGetLastError();
+}
+
 int launch_ffdtf_norm(const NormArgs& a, hipStream_t st) {
   if (a.n_items == 0) return 0;
   if (a.normalise)

@@ -78,6 +78,11 @@ struct NormArgs {
 };
 int launch_ffdtf_norm(const NormArgs& a, hipStream_t st);
 
+int launch_trial_mean(const double* in, double* out, long long n, int trials, hipStream_t st);
+int launch_ddtf(const double* ff, const double* kappa, double* out, long long n, hipStream_t st);
+int launch_band_sums(const double* in, const int* lo, const int* hi, double* out, long long rows, int F, int nb,
+                     hipStream_t st);
+
 // complex [n_items][F][MP][MP] -> complex [n_items][m][m][F]
 int launch_transpose_c128(const double* in, double* out, long long n_items, int F, int m, int m_pad, hipStream_t st);
 

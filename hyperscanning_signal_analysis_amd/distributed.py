@@ -17,7 +17,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "shard_dyads", "shard_windows", "band_integrate", "gather_to_root", "DEFAULT_BANDS"]
+__all__ = ["shard_range", "shard_dyads", "shard_windows", "shard_window_items", "band_bins", "band_integrate",
+           "gather_to_root", "DEFAULT_BANDS"]
 
 # delta, theta, alpha, beta, gamma edges in Hz (inclusive low, exclusive high)
 DEFAULT_BANDS = ((0.5, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 128.5))
@@ -41,17 +42,45 @@ def shard_windows(positions, world: int, rank: int):
     return np.asarray(positions)[lo:hi]
 
 
-def band_integrate(ff: torch.Tensor, freqs, bands=DEFAULT_BANDS) -> torch.Tensor:
-    """(..., m, m, F) -> (..., m, m, n_bands): sum of ffDTF over the frequency bins of each band."""
+def shard_window_items(positions, window_size: int, world: int, rank: int):
+    """Window-range shard of ONE recording for `rank`: (sample_lo, sample_hi, rebased_starts, (win_lo, win_hi)).
+
+    The rank needs only samples [sample_lo, sample_hi) of the recording -- its own windows plus the read-only
+    overlap with the neighbour's first window -- and finds its windows at `rebased_starts` inside that slice
+    (secondary partitioning: BASELINE config 2 at 2 / 4 / 8 GPUs).  Windows of a shard computed
+    from the slice equal the same windows computed from the whole recording bit for bit: every kernel reads only
+    the samples of its own window.  An empty shard (more ranks than windows) gives (0, 0, [], (lo, lo))."""
+    pos = np.asarray(positions, dtype=np.int64)
+    lo, hi = shard_range(len(pos), world, rank)
+    if hi == lo:
+        return 0, 0, pos[:0], (lo, lo)
+    mine = pos[lo:hi]
+    s_lo, s_hi = int(mine.min()), int(mine.max()) + int(window_size)
+    return s_lo, s_hi, mine - s_lo, (lo, hi)
+
+
+def band_bins(freqs, bands=DEFAULT_BANDS):
+    """Bin ranges [lo, hi) of each band on the frequency grid (empty band: lo == hi).  Host-side index logic."""
     f = np.asarray(freqs, dtype=np.float64)
-    outs = []
-    for lo, hi in bands:
-        idx = np.flatnonzero((f >= lo) & (f < hi))
+    lo, hi = [], []
+    for b_lo, b_hi in bands:
+        idx = np.flatnonzero((f >= b_lo) & (f < b_hi))
         if len(idx) == 0:
-            outs.append(torch.zeros(ff.shape[:-1], dtype=ff.dtype, device=ff.device))
+            lo.append(0); hi.append(0)
         else:
-            outs.append(ff[..., int(idx[0]):int(idx[-1]) + 1].sum(dim=-1))
-    return torch.stack(outs, dim=-1)
+            if not np.array_equal(idx, np.arange(idx[0], idx[-1] + 1)):
+                raise ValueError("band_bins needs an ascending frequency grid")
+            lo.append(int(idx[0])); hi.append(int(idx[-1]) + 1)
+    return np.asarray(lo, dtype=np.int32), np.asarray(hi, dtype=np.int32)
+
+
+def band_integrate(ff: torch.Tensor, freqs, bands=DEFAULT_BANDS, engine=None) -> torch.Tensor:
+    """(..., m, m, F) device tensor -> (..., m, m, n_bands): sum of ffDTF over the bins of each band
+    (`hmv_band_sums_f64`; the product has no CPU path)."""
+    from .engine import default_engine
+    eng = engine or default_engine()
+    lo, hi = band_bins(freqs, bands)
+    return eng.band_sums(ff, lo, hi)
 
 
 def gather_to_root(local: torch.Tensor, dst: int = 0):

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["Engine", "default_engine", "SingularMatrixError"]
+__all__ = ["Engine", "default_engine", "SingularMatrixError", "validate_items"]
 
 
 class SingularMatrixError(np.linalg.LinAlgError):
@@ -27,6 +27,29 @@ class SingularMatrixError(np.linalg.LinAlgError):
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+def validate_items(x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int):
+    """Refuse window descriptors the kernels would read out of bounds with, BEFORE anything is launched: wrong
+    dtype / device, a recording index outside x, a window that does not lie inside its recording (one tiny
+    reduction on the tensors' device).  x: (n_rec, m, T).  Pure tensor logic: also runs on CPU tensors."""
+    n_rec, m, T = x.shape
+    for name, t in (("item_rec", item_rec), ("item_start", item_start)):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.int64 or t.device != x.device or t.dim() != 1:
+            raise ValueError(f"{name} must be a 1-D int64 tensor on {x.device}")
+    if item_rec.numel() != item_start.numel():
+        raise ValueError("item_rec and item_start must have the same length")
+    if int(n) <= int(p):
+        raise ValueError(f"window length ({n}) must exceed the model order ({p})")
+    if int(n) > T:
+        raise ValueError(f"window length ({n}) exceeds the recording length ({T})")
+    if item_rec.numel() == 0:
+        return
+    lim = torch.stack([item_rec.min(), item_rec.max(), item_start.min(), item_start.max()]).cpu().tolist()
+    if lim[0] < 0 or lim[1] >= n_rec:
+        raise ValueError(f"item_rec must lie in [0, {n_rec}), got [{lim[0]}, {lim[1]}]")
+    if lim[2] < 0 or lim[3] + int(n) > T:
+        raise ValueError(f"windows [start, start + {n}) must lie in [0, {T}), got starts in [{lim[2]}, {lim[3]}]")
 
 
 class Engine:
@@ -65,9 +88,25 @@ class Engine:
         return self._ws
 
     @staticmethod
-    def raise_on_info(info: torch.Tensor, what: str):
-        if bool((info != 0).any().item()):
-            raise SingularMatrixError("Singular matrix")
+    def raise_on_info(info: torch.Tensor, what: str, per_item: int = 1):
+        """LAPACK-style info array -> the reference's LinAlgError("Singular matrix") (np.linalg.solve / inv).
+        The exception additionally carries which items failed (`.items`, `.info`: first bad pivot column, 1-based;
+        with `per_item` = F for the per-frequency inverses, `.freqs` too)."""
+        bad = torch.nonzero(info != 0).flatten()
+        if bad.numel() == 0:
+            return
+        idx = bad.cpu().numpy()
+        err = SingularMatrixError("Singular matrix")
+        err.stage = what
+        err.items = np.unique(idx // per_item)
+        err.freqs = (idx % per_item) if per_item > 1 else None
+        err.info = info[bad].cpu().numpy()
+        err.args = ("Singular matrix", f"{what}: {len(err.items)} item(s) failed, first: item {int(err.items[0])}"
+                    + (f" frequency {int(err.freqs[0])}" if per_item > 1 else "") + f" pivot column {int(err.info[0])}")
+        raise err
+
+    def check_items(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int):
+        validate_items(x, item_rec, item_start, n, p)
 
     # ------------------------------------------------------------------ K1
     def lagcov(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int):
@@ -76,6 +115,7 @@ class Engine:
         x = x if x.stride(2) == 1 else x.contiguous()
         n_rec, m, T = x.shape
         mp = self.pad(m)
+        self.check_items(x, item_rec, item_start, n, p)
         n_items = int(item_rec.numel())
         R = self.empty(n_items, p + 1, mp, mp)
         with torch.cuda.device(self.device):
@@ -84,6 +124,15 @@ class Engine:
                                          self.stream())
         _lib.check(rc, "hmv_lagcov_f64")
         return R
+
+    def trial_mean(self, R: torch.Tensor, m: int):
+        """(trials, p+1, MP, MP) -> (1, p+1, MP, MP): count_corr's average over trials (mtmvar.py:78-85)."""
+        trials, p1, mp, _ = R.shape
+        out = self.empty(1, p1, mp, mp)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_trial_mean_f64(R.data_ptr(), trials, m, p1 - 1, out.data_ptr(), self.stream())
+        _lib.check(rc, "hmv_trial_mean_f64")
+        return out
 
     # ------------------------------------------------------------------ K2
     def yw_solve(self, R: torch.Tensor, m: int, want_logdet: bool = False, flags: int = 0):
@@ -190,6 +239,34 @@ class Engine:
         _lib.check(rc, "hmv_partial_coherence_c128")
         return self.to_mmf_complex(kap, m), info
 
+    def ddtf(self, ff: torch.Tensor, kappa: torch.Tensor):
+        """ffDTF (items, m, m, F) real x |partial coherence| (items, m, m, F) complex128 -> dDTF (mtmvar.py:341-385)."""
+        n_items, m, _, F = ff.shape
+        ff = ff.contiguous()
+        kr = torch.view_as_real(kappa.contiguous())
+        out = self.empty(n_items, m, m, F)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_ddtf_f64(ff.data_ptr(), kr.data_ptr(), out.data_ptr(), n_items, m, F, self.stream())
+        _lib.check(rc, "hmv_ddtf_f64")
+        return out
+
+    def band_sums(self, ff: torch.Tensor, bin_lo, bin_hi):
+        """(..., F) -> (..., n_bands): sums over the bin ranges [bin_lo[b], bin_hi[b])."""
+        F = ff.shape[-1]
+        ff = ff.contiguous()
+        lo = torch.as_tensor(np.asarray(bin_lo, dtype=np.int32)).to(self.device)
+        hi = torch.as_tensor(np.asarray(bin_hi, dtype=np.int32)).to(self.device)
+        if bool((lo < 0).any()) or bool((hi > F).any()) or bool((hi < lo).any()):
+            raise ValueError("band bin ranges must satisfy 0 <= lo <= hi <= F")
+        nb = int(lo.numel())
+        rows = ff.numel() // F if F else 0
+        out = self.empty(*ff.shape[:-1], nb)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_band_sums_f64(ff.data_ptr(), rows, F, lo.data_ptr(), hi.data_ptr(), nb, out.data_ptr(),
+                                            self.stream())
+        _lib.check(rc, "hmv_band_sums_f64")
+        return out
+
     def gpdc(self, A: torch.Tensor, V: torch.Tensor, m: int):
         """A (items, F, MP, MP, 2) from `transfer(want_A=True)`, V (items, MP, MP) -> GPDC (items, m, m, F)."""
         n_items, F, mp, _, _ = A.shape
@@ -218,6 +295,9 @@ class Engine:
                       flags: int = 0):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
+        check: True raises numpy.linalg.LinAlgError("Singular matrix") if ANY window failed, like the reference's
+        np.linalg.solve / inv (the exception names the windows); "nan" returns every window and NaN-fills the
+        failed ones; False skips the check (and its synchronisation).
         overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the
         chip, then runs as two half-batches that interleave on the device (see include/hypermvar.h).
         flags: option bits of include/hypermvar.h (`_lib.FLAG_*`); 0 = the fast defaults.
@@ -228,6 +308,7 @@ class Engine:
         x = x if x.stride(2) == 1 else x.contiguous()
         n_rec, m, T = x.shape
         mp = self.pad(m)
+        self.check_items(x, item_rec, item_start, n, p)
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
@@ -253,9 +334,13 @@ class Engine:
                 info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
                 k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
         _lib.check(rc, "hmv_sliding_ffdtf_f64")
-        if check:
-            self.raise_on_info(info_yw, "yw")
-            self.raise_on_info(info_tf, "tf")
+        if check == "nan":          # keep the good windows, NaN-fill the ones whose fit or inverse was singular
+            badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
+            if bool(badw.any()):
+                out[badw] = float("nan")
+        elif check:
+            self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
+            self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
         if return_ar:
             return out, ar, V, (info_yw, info_tf)
         return out

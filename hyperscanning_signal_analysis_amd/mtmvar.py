@@ -46,7 +46,7 @@ def _lagcov_mean(data, p: int, eng: Engine):
     start = torch.zeros(trials, dtype=torch.int64, device=eng.device)
     R = eng.lagcov(x, rec, start, n, p)
     if trials > 1:
-        R = R.sum(dim=0, keepdim=True) / trials          # mtmvar.py:78-85
+        R = eng.trial_mean(R, m)                          # mtmvar.py:78-85
     return R, m, n
 
 
@@ -116,7 +116,7 @@ def mvar_transfer_function(ar_coeffs, freqs, fs):
     arp[0, :m, :m, :] = torch.as_tensor(ar_coeffs).to(eng.device)
     tw = eng.twiddles(freqs, fs, p)
     out = eng.transfer(arp, m, tw, want_P=False, want_H=True, want_A=True)
-    eng.raise_on_info(out["info"], "mvar_transfer_function")
+    eng.raise_on_info(out["info"], "mvar_transfer_function (inverse of A(f))", per_item=len(np.atleast_1d(freqs)))
     H = eng.to_mmf_complex(out["H"], m)[0].cpu().numpy()
     A = eng.to_mmf_complex(out["A"], m)[0].cpu().numpy()
     return H, A
@@ -137,7 +137,7 @@ def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
     need_H = ("H" in want) or need_S
     need_P = any(k in want for k in ("dtf", "ffdtf", "ddtf"))
     t = eng.transfer(ar, m, tw, want_P=need_P, want_H=need_H, want_A=any(k in want for k in ("A", "gpdc")))
-    eng.raise_on_info(t["info"], "transfer")
+    eng.raise_on_info(t["info"], "mvar_transfer_function (inverse of A(f))", per_item=len(np.atleast_1d(freqs)))
     res = {}
     if "ar" in want:
         res["ar"] = ar[0, :m, :m, :].cpu().numpy()
@@ -164,7 +164,7 @@ def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
             if "pcoh" in want:
                 res["pcoh"] = kappa[0].cpu().numpy()
             if "ddtf" in want:
-                res["ddtf"] = (ff[0] * kappa[0].abs()).cpu().numpy()
+                res["ddtf"] = eng.ddtf(ff, kappa)[0].cpu().numpy()
     if "gpdc" in want:
         res["gpdc"] = eng.gpdc(t["A"], V, m)[0].cpu().numpy()
     return res
@@ -235,18 +235,24 @@ def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):
     eng = default_engine()
     _, _, logdet, _, _ = _fit(data, int(max_model_order), eng, want_logdet=True)
     crit = logdet[0].cpu().numpy() + pen
-    optimal_model_range = model_order_range[np.argmin(crit)]
+    best = int(np.argmin(crit))                     # first minimum, like the reference's argmin (Q7)
+    p_opt = model_order_range[best]
     if plot:
-        import matplotlib.pyplot as plt
-        plt.figure()
-        plt.plot(model_order_range, crit, marker='o')
-        plt.plot(optimal_model_range, np.min(crit), 'ro')
-        plt.xlabel('Model order p')
-        plt.ylabel(f'{crit_type} criterion')
-        plt.title(f'MVAR Model Order Selection ({crit_type}). The best order = {optimal_model_range}')
-        plt.grid(True)
-        plt.show()
-    return crit, model_order_range, optimal_model_range
+        _criterion_figure(model_order_range, crit, best, crit_type)
+    return crit, model_order_range, p_opt
+
+
+def _criterion_figure(orders, crit, best, crit_type):
+    """The figure `mvar_criterion(..., plot=True)` pops up: criterion against model order, the minimum marked."""
+    import matplotlib.pyplot as plt
+    fig, ax = plt.subplots()
+    ax.plot(orders, crit, "o-")
+    ax.plot([orders[best]], [crit[best]], "ro")
+    ax.set(xlabel="Model order p", ylabel=f"{crit_type} criterion",
+           title=f"MVAR Model Order Selection ({crit_type}). The best order = {orders[best]}")
+    ax.grid(True)
+    plt.show()
+    return fig
 
 
 def mvar_plot(spectra, ff_dtf, freqs, chan_names=None, top_title=""):

@@ -16,35 +16,34 @@ __all__ = ["window_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf
 
 
 def window_positions(T: int, n_windows: int = 3, window_size=None):
-    """Start positions and window length of `_create_windows` (eeg_alpha_ibi_ffdtf.py:451-518)."""
+    """Start positions and window length of `_create_windows` (eeg_alpha_ibi_ffdtf.py:451-518): `n_windows` windows of
+    `window_size` samples whose starts are spread evenly (integer-truncated) from 0 to T - window_size, so the last
+    window ends exactly at T.  Same ValueError texts as the reference (pinned by tests/golden/g6_errors.npz)."""
+    T, n_windows = int(T), int(n_windows)
     if window_size is None:
-        if T % n_windows != 0:
+        window_size, rest = divmod(T, n_windows)
+        if rest:
             raise ValueError(
                 f"Cannot evenly divide signal of length {T} into {n_windows} "
                 f"non-overlapping windows. Provide a specific window_size."
             )
-        window_size = T // n_windows
-    else:
-        min_required_size = (T + n_windows - 1) // n_windows
-        if window_size < min_required_size:
-            raise ValueError(
-                f"window_size={window_size} is too short. To cover {T} samples "
-                f"with {n_windows} windows without leaving gaps, the minimum "
-                f"window_size is {min_required_size}."
-            )
-        if window_size > T:
-            raise ValueError(f"window_size ({window_size}) cannot exceed signal length ({T}).")
-    max_start = T - window_size
-    if max_start < n_windows - 1 and n_windows > 1:
+    elif window_size > T:
+        # (the reference tests "too short" first; a size cannot be both, so the order is immaterial)
+        raise ValueError(f"window_size ({window_size}) cannot exceed signal length ({T}).")
+    elif window_size * n_windows < T:          # fewer than ceil(T / n_windows) samples per window: gaps
+        raise ValueError(
+            f"window_size={window_size} is too short. To cover {T} samples "
+            f"with {n_windows} windows without leaving gaps, the minimum "
+            f"window_size is {-(-T // n_windows)}."
+        )
+    last_start = T - window_size
+    if n_windows > 1 and last_start < n_windows - 1:
         raise ValueError(
             f"window_size={window_size} is too large to generate {n_windows} "
             f"distinct windows. Decrease window_size or n_windows."
         )
-    if n_windows == 1:
-        positions = np.array([0], dtype=int)
-    else:
-        positions = np.linspace(0, max_start, n_windows, dtype=int)
-    return positions, int(window_size)
+    starts = np.linspace(0, last_start, n_windows, dtype=int) if n_windows > 1 else np.zeros(1, dtype=int)
+    return starts, int(window_size)
 
 
 def create_windows(signals, n_windows=3, window_size=None):

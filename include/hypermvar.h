@@ -102,6 +102,20 @@ int hmv_partial_coherence_c128(const double* Sinv, const double* detph, double* 
                                int F, void* stream);
 int hmv_gpdc_f64(const double* A, const double* V, double* G, int64_t n_items, int m, int F, void* stream);
 
+/* Small elementwise companions, so that no arithmetic of the path is left to the host framework:
+ * hmv_trial_mean_f64: R_mean[l] = (R[0][l] + ... + R[T-1][l]) / T over the lag covariances of T trials, the
+ *   multi-trial average of count_corr (src/mtmvar.py:54-85; totals accumulated trial by trial, then divided).
+ *   R_trials: [n_trials][p+1][MP][MP] (hmv_lagcov_f64 with one item per trial), R_mean: [p+1][MP][MP].
+ * hmv_ddtf_f64: ddtf = ffdtf * |kappa|, the product of direct_dtf (src/mtmvar.py:341-385); ffdtf real and kappa
+ *   complex128, both [item][m][m][F] (the reference's layout).
+ * hmv_band_sums_f64: out[row][b] = sum_{bin_lo[b] <= f < bin_hi[b]} ffdtf[row][f] for the n_rows = items*m*m rows
+ *   of an [item][m][m][F] array (bin_lo / bin_hi: int32 device arrays): the band-integrated ffDTF that is
+ *   gathered across GPUs (the reference's graph plots integrate ffDTF over a band, src/mtmvar.py:984-987). */
+int hmv_trial_mean_f64(const double* R_trials, int64_t n_trials, int m, int p, double* R_mean, void* stream);
+int hmv_ddtf_f64(const double* ffdtf, const double* kappa, double* ddtf, int64_t n_items, int m, int F, void* stream);
+int hmv_band_sums_f64(const double* ffdtf, int64_t n_rows, int F, const int32_t* bin_lo, const int32_t* bin_hi,
+                      int n_bands, double* out, void* stream);
+
 /* Multitaper PSD.  Replaces compute_psd_multitaper (src/psd.py:7-33), i.e.
  * mne.time_frequency.psd_array_multitaper(data, sfreq, fmin, fmax, bandwidth) of mne==1.11.0 with its defaults
  * (remove_dc, non-adaptive eigenvalue weights, normalization "length").  mne is NOT available offline: PARITY

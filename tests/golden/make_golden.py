@@ -16,8 +16,10 @@ Fixture list:
   g4_config4.npz    4x480 z-scored block, `_create_windows(.., 3, None)` and `(.., 5, 160)`,
                     per-window + global ff_dtf / spectra at p=5, freq grid quirk Q9.
   g5_multitrial.npz multi-trial input (5, 400, 4): r_left, r_right, r, ar, V.
-  g6_errors.npz     inputs that make the reference raise (singular window), plus window-geometry
-                    error cases (recorded as message strings).
+  g6_errors.npz     inputs that make the reference raise (dead channel), a rank-deficient window on which it does
+                    NOT raise (what it returns is recorded), three nearly collinear windows (cond 1e5 .. 1e13) with
+                    the reference's ar / V, plus window-geometry error cases (recorded as message strings).
+                    `python tests/golden/make_golden.py g6` writes only this.
   g7_connectivity.npz  partial_coherence / direct_dtf / gen_partial_directed_coherence on
                     the G1 signal (m=3, p=4), a 4x480 block (p=5), a 7-channel VAR(3), and partial_coherence of
                     an arbitrary complex 5x5x6 array.  `python tests/golden/make_golden.py g7` writes only this.
@@ -126,12 +128,67 @@ def make_g8():
     print("g8_faa_chain.npz written")
 
 
+def make_g6(pipe=None, x4=None):
+    """Error behaviour and ill-conditioned windows.  What the reference's dgesv RETURNS on a rank-deficient or nearly
+    collinear window is recorded too (xs_ar / xs_V, nc*_ar / nc*_V with the condition number of r_left): on the
+    exactly deficient window the numbers are rounding noise amplified by 1e16 and are recorded as evidence only."""
+    if pipe is None:
+        pipe = ref_pipe.EEG_IBI_FFDTF_Pipeline.__new__(ref_pipe.EEG_IBI_FFDTF_Pipeline)
+    if x4 is None:
+        x4 = small_var(44, 4, 5, 480)
+    g6 = {}
+    xs = small_var(66, 4, 2, 300)
+    xs[3] = xs[0] + xs[1]                    # exactly rank-deficient window
+    try:
+        ar_s, V_s = ref.ar_coeff(xs, 3)
+        g6["singular_raises"] = "no"
+        g6["xs_ar"], g6["xs_V"] = ar_s, V_s
+        g6["xs_cond"] = np.linalg.cond(ref.count_corr(xs[:, :, None], 3, 1)[0])
+    except np.linalg.LinAlgError as e:
+        g6["singular_raises"] = f"LinAlgError:{e}"
+    # nearly collinear channels (bridged electrodes / re-referenced montages): channel 3 = ch0 + ch1 + eps * noise
+    rng = np.random.default_rng(660)
+    noise = rng.standard_normal(300)
+    for k, eps in enumerate((1e-2, 1e-4, 1e-6)):
+        xn = small_var(66, 4, 2, 300)
+        xn[3] = xn[0] + xn[1] + eps * noise
+        ar_n, V_n = ref.ar_coeff(xn, 3)
+        g6[f"nc{k}_x"], g6[f"nc{k}_ar"], g6[f"nc{k}_V"] = xn, ar_n, V_n
+        g6[f"nc{k}_cond"] = np.linalg.cond(ref.count_corr(xn[:, :, None], 3, 1)[0])
+        g6[f"nc{k}_eps"] = eps
+    xz = small_var(67, 4, 2, 300)
+    xz[2] = 0.0                               # dead channel -> exactly singular normal equations
+    try:
+        ref.ar_coeff(xz, 3)
+        g6["deadchan_raises"] = "no"
+    except np.linalg.LinAlgError as e:
+        g6["deadchan_raises"] = f"LinAlgError:{e}"
+    try:
+        ref.mvar_criterion(x4, 3, "BIC", False)
+        g6["badcrit"] = "no"
+    except ValueError as e:
+        g6["badcrit"] = f"ValueError:{e}"
+    msgs = []
+    for (T, nw, ws) in [(481, 3, None), (480, 3, 100), (480, 3, 481), (480, 5, 478)]:
+        try:
+            pipe._create_windows(np.zeros((2, T)), nw, ws)
+            msgs.append("ok")
+        except ValueError as e:
+            msgs.append(str(e))
+    g6["window_errors"] = np.array(msgs)
+    np.savez_compressed(os.path.join(HERE, "g6_errors.npz"), xs=xs, xz=xz, **g6)
+    print("g6_errors.npz written:", {k: (float(g6[k]) if k.endswith("cond") else None) for k in g6 if k.endswith("cond")})
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g7":
         make_g7()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         make_g8()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g6":
+        make_g6()
         return
     out = {}
     # ------------------------------------------------------------------ G1
@@ -214,36 +271,7 @@ def main():
     H, A = ref.mvar_transfer_function(ar, np.arange(1, 30.0), 64.0)
     np.savez_compressed(os.path.join(HERE, "g5_multitrial.npz"), x=x5, r_left=rl, r_right=rr, r=r0, ar=ar, V=V,
                         H=H, freqs=np.arange(1, 30.0), fs=64.0)
-    # ------------------------------------------------------------------ G6
-    g6 = {}
-    xs = small_var(66, 4, 2, 300)
-    xs[3] = xs[0] + xs[1]                    # exactly rank-deficient window
-    try:
-        ref.ar_coeff(xs, 3)
-        g6["singular_raises"] = "no"
-    except np.linalg.LinAlgError as e:
-        g6["singular_raises"] = f"LinAlgError:{e}"
-    xz = small_var(67, 4, 2, 300)
-    xz[2] = 0.0                               # dead channel -> exactly singular normal equations
-    try:
-        ref.ar_coeff(xz, 3)
-        g6["deadchan_raises"] = "no"
-    except np.linalg.LinAlgError as e:
-        g6["deadchan_raises"] = f"LinAlgError:{e}"
-    try:
-        ref.mvar_criterion(x4, 3, "BIC", False)
-        g6["badcrit"] = "no"
-    except ValueError as e:
-        g6["badcrit"] = f"ValueError:{e}"
-    msgs = []
-    for (T, nw, ws) in [(481, 3, None), (480, 3, 100), (480, 3, 481), (480, 5, 478)]:
-        try:
-            pipe._create_windows(np.zeros((2, T)), nw, ws)
-            msgs.append("ok")
-        except ValueError as e:
-            msgs.append(str(e))
-    g6["window_errors"] = np.array(msgs)
-    np.savez_compressed(os.path.join(HERE, "g6_errors.npz"), xs=xs, xz=xz, **g6)
+    make_g6(pipe, x4)
     make_g7()
     make_g8()
     for f in sorted(os.listdir(HERE)):

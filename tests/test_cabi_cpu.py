@@ -70,3 +70,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_bad_window_descriptors_are_refused_before_any_launch():
+    """item_rec / item_start go straight into kernel address arithmetic, so dtype, device, recording
+    index and window bounds are checked on the host side first (pure tensor logic: runs on CPU tensors here)."""
+    import torch
+    from hyperscanning_signal_analysis_amd.engine import validate_items
+    x = torch.zeros(2, 4, 1000, dtype=torch.float64)
+    rec = torch.tensor([0, 1, 1], dtype=torch.int64)
+    st = torch.tensor([0, 10, 800], dtype=torch.int64)
+    validate_items(x, rec, st, 200, 5)                                   # fine: last window ends at 1000
+    validate_items(x, rec[:0], st[:0], 200, 5)                           # empty batch
+    for bad_rec, bad_st, n, p, msg in [
+        (rec.to(torch.int32), st, 200, 5, "int64"),
+        (rec, st.to(torch.float64), 200, 5, "int64"),
+        (rec, st[:2], 200, 5, "same length"),
+        (torch.tensor([0, 2, 1]), st, 200, 5, "item_rec must lie"),
+        (torch.tensor([0, -1, 1]), st, 200, 5, "item_rec must lie"),
+        (rec, torch.tensor([0, 10, 801]), 200, 5, "must lie in"),
+        (rec, torch.tensor([-1, 10, 800]), 200, 5, "must lie in"),
+        (rec, st, 5, 5, "exceed the model order"),
+        (rec, st, 1001, 5, "exceeds the recording length"),
+    ]:
+        with pytest.raises(ValueError, match=msg):
+            validate_items(x, bad_rec, bad_st, n, p)

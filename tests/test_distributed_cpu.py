@@ -1,5 +1,5 @@
 """Multi-rank layout on CPU (gloo, world_size 2): sharding is balanced and disjoint, the single gather to
-rank 0 returns the per-rank results in rank order, band integration matches a NumPy reduction."""
+rank 0 returns the per-rank results in rank order, band bins and window-range shards are right."""
 import os
 import socket
 
@@ -25,16 +25,32 @@ def test_shard_ranges_cover_everything():
     assert list(hd.shard_windows(pos, 2, 1)) == list(pos[5:])
 
 
-def test_band_integrate_matches_numpy():
-    rng = np.random.default_rng(0)
-    ff = rng.random((3, 4, 4, 256))
+def test_band_bins_tile_the_grid():
     freqs = 0.5 * np.arange(1, 257)
-    got = hd.band_integrate(torch.as_tensor(ff), freqs).numpy()
-    assert got.shape == (3, 4, 4, len(hd.DEFAULT_BANDS))
-    for b, (lo, hi) in enumerate(hd.DEFAULT_BANDS):
-        sel = (freqs >= lo) & (freqs < hi)
-        assert np.allclose(got[..., b], ff[..., sel].sum(-1), rtol=1e-13)
-    assert np.allclose(got.sum(-1), ff.sum(-1), rtol=1e-12)      # the bands tile 0.5 .. 128 Hz
+    lo, hi = hd.band_bins(freqs)
+    assert lo.dtype == np.int32 and len(lo) == len(hd.DEFAULT_BANDS)
+    for b, (f_lo, f_hi) in enumerate(hd.DEFAULT_BANDS):
+        sel = np.flatnonzero((freqs >= f_lo) & (freqs < f_hi))
+        assert (lo[b], hi[b]) == (sel[0], sel[-1] + 1)
+    assert lo[0] == 0 and hi[-1] == 256 and np.array_equal(lo[1:], hi[:-1])      # the bands tile 0.5 .. 128 Hz
+    lo2, hi2 = hd.band_bins(freqs, bands=((200.0, 300.0),))                        # empty band
+    assert lo2[0] == hi2[0]
+
+
+def test_shard_window_items_rebases_starts():
+    pos = np.arange(0, 300_000 - 999, 500)                    # 599 windows of 1000, hop 500
+    covered = []
+    for world in (1, 2, 4, 8, 3):
+        covered = []
+        for r in range(world):
+            s_lo, s_hi, starts, (w_lo, w_hi) = hd.shard_window_items(pos, 1000, world, r)
+            assert s_lo == pos[w_lo] and s_hi == pos[w_hi - 1] + 1000
+            assert starts[0] == 0 and np.array_equal(starts + s_lo, pos[w_lo:w_hi])
+            assert s_hi - s_lo == 500 * (w_hi - w_lo) + 500           # own windows + the one-hop halo
+            covered += list(range(w_lo, w_hi))
+        assert covered == list(range(599))
+    s_lo, s_hi, starts, span = hd.shard_window_items(pos[:2], 1000, 4, 3)          # more ranks than windows
+    assert (s_lo, s_hi, len(starts)) == (0, 0, 0) and span[0] == span[1]
 
 
 def _free_port():
