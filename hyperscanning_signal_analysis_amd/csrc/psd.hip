@@ -91,11 +91,15 @@ int launch_psd(const double* x, long long n_ch, long long n, long long ld, const
         plan = it->second;
       }
     }
-    if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return -21;
     hipLaunchKernelGGL(psd_mean_kernel, dim3((unsigned)c), dim3(256), 0, st, x + (size_t)c0 * ld, ld, n, mean);
     hipLaunchKernelGGL(psd_taper_kernel, dim3((unsigned)((n + 255) / 256), K, (unsigned)c), dim3(256), 0, st,
                        x + (size_t)c0 * ld, ld, mean, tapers, n, K, y);
-    if (hipfftExecD2Z(plan, y, reinterpret_cast<hipfftDoubleComplex*>(X)) != HIPFFT_SUCCESS) return -22;
+    {   // a cached plan carries ONE stream: binding it and enqueueing on it are one critical section, so two host
+        // threads that share the plan on different streams cannot re-bind it under each other
+      std::lock_guard<std::mutex> lock(g_plan_mutex);
+      if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return -21;
+      if (hipfftExecD2Z(plan, y, reinterpret_cast<hipfftDoubleComplex*>(X)) != HIPFFT_SUCCESS) return -22;
+    }
     hipLaunchKernelGGL(psd_power_kernel, dim3((unsigned)((nb + 255) / 256), (unsigned)c), dim3(256), 0, st, X, w, nfreq, n, K,
                        lo, nb, psd + (size_t)c0 * nb, nb);
   }

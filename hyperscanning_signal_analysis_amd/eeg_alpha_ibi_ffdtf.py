@@ -182,7 +182,7 @@ class EEG_IBI_FFDTF_Pipeline:
 
     def _order_for(self, signals, max_model_order, crit_type):
         if self.ar_p is None:
-            _, _, p_opt = mtmvar.mvar_criterion(signals, max_model_order, crit_type, plot=False)
+            _, _, p_opt = mtmvar.mvar_criterion(signals, max_model_order, crit_type, plot=False, engine=self._engine)
             return int(p_opt)
         return self.ar_p
 
@@ -191,7 +191,7 @@ class EEG_IBI_FFDTF_Pipeline:
         """(ff_dtf, spectra, p_opt) of one segment (ref :521-634); ONE fit feeds both products."""
         freqs = self._freqs()
         p_opt = self._order_for(signals, max_model_order, crit_type)
-        res = mtmvar.mvar_analysis(signals, freqs, fs, p_opt, want=("ffdtf", "spectra"))
+        res = mtmvar.mvar_analysis(signals, freqs, fs, p_opt, want=("ffdtf", "spectra"), engine=self._engine)
         ff_dtf, spectra = res["ffdtf"], res["spectra"]
         if plot or save_plot:
             self._figure(dyad, spectra, ff_dtf, freqs, chan_names, plot, save_plot, save_path, fig_name)
@@ -203,7 +203,8 @@ class EEG_IBI_FFDTF_Pipeline:
         orders = [self._order_for(w, max_model_order, crit_type) for w in windows]
         same = len(set(orders)) == 1 and len({w.shape for w in windows}) == 1
         if not same:
-            out = [mtmvar.mvar_analysis(w, freqs, fs, p, want=("ffdtf", "spectra")) for w, p in zip(windows, orders)]
+            out = [mtmvar.mvar_analysis(w, freqs, fs, p, want=("ffdtf", "spectra"), engine=self._engine)
+                   for w, p in zip(windows, orders)]
             return [o["ffdtf"] for o in out], [o["spectra"] for o in out], orders
         from .engine import default_engine
         import torch
@@ -300,7 +301,7 @@ class EEG_IBI_FFDTF_Pipeline:
                 sig = (sig - np.mean(sig, axis=1, keepdims=True)) / np.std(sig, axis=1, keepdims=True)
                 print(" [OK] Pre-processing complete (Alpha -> FAA -> Downsample -> Crop -> Z-Score)")
                 if self.ar_p is not None:
-                    _, _, suggested_p = mtmvar.mvar_criterion(sig, 20, "AIC", plot=False)
+                    _, _, suggested_p = mtmvar.mvar_criterion(sig, 20, "AIC", plot=False, engine=self._engine)
                     print(f" [INFO] AIC suggested p={suggested_p} for global signal. Forcing fixed p={self.ar_p}.")
                 windows = self._create_windows(sig, self.n_windows, self.window_size)
                 out_dir = self.output_ffDTF_folder / dyad

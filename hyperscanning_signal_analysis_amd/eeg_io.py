@@ -12,16 +12,14 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["preprocess_eeg", "load_eeg_signals", "load_dyad_block"]
+__all__ = ["filter_eeg", "preprocess_eeg", "load_eeg_signals", "load_dyad_block"]
 
 
-def preprocess_eeg(data_tc, time_s, channel_names, fs, event_duration_s=None, channel_subset=None,
-                   low_cutoff_hz=None, high_cutoff_hz=None, source="<array>"):
-    """(time, channel) samples -> (signals (n_chan, n_samp) z-scored, names, time_s trimmed)."""
+def filter_eeg(data_tc, fs, low_cutoff_hz=None, high_cutoff_hz=None):
+    """The filter sequence of `load_eeg_signals` (mne_bridge.py:152-183) on (time, channel) samples: zero-phase
+    Butterworth-4 high-pass, low-pass, then the 50 Hz notch (Q = 15) when 50 Hz is below Nyquist."""
     from scipy.signal import butter, filtfilt, iirnotch
     x = np.asarray(data_tc, dtype=np.float64)
-    t = np.asarray(time_s, dtype=np.float64)
-    names = [str(c) for c in channel_names]
     nyq = fs / 2.0
     for cutoff, kind, label in ((low_cutoff_hz, "highpass", "low_cutoff_hz"), (high_cutoff_hz, "lowpass", "high_cutoff_hz")):
         if cutoff is None:
@@ -34,6 +32,15 @@ def preprocess_eeg(data_tc, time_s, channel_names, fs, event_duration_s=None, ch
     if 50.0 < nyq:
         b, a = iirnotch(50.0, Q=15, fs=fs)
         x = filtfilt(b, a, x, axis=0)
+    return x
+
+
+def preprocess_eeg(data_tc, time_s, channel_names, fs, event_duration_s=None, channel_subset=None,
+                   low_cutoff_hz=None, high_cutoff_hz=None, source="<array>"):
+    """(time, channel) samples -> (signals (n_chan, n_samp) z-scored, names, time_s trimmed)."""
+    x = filter_eeg(data_tc, fs, low_cutoff_hz, high_cutoff_hz)
+    t = np.asarray(time_s, dtype=np.float64)
+    names = [str(c) for c in channel_names]
     if event_duration_s is None:
         event_duration_s = float(t[-1])
     keep_t = (t >= 0.0) & (t <= event_duration_s)

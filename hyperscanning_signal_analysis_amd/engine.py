@@ -60,8 +60,8 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.pivot_tau = float(pivot_tau)
         self.max_workspace_bytes = int(max_workspace_bytes)
-        self._ws = None
-        self._aux = None        # second HIP stream for chunk overlap in the fused path
+        self._ws = {}
+        self._aux = {}        # second HIP stream for chunk overlap in the fused path
 
     # ------------------------------------------------------------------ helpers
     def stream(self):
@@ -82,10 +82,14 @@ class Engine:
         return mp
 
     def _workspace(self, nbytes: int):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Cached scratch of the fused call, one buffer per HIP stream: two calls on different streams never share
+        (and so never race on) a workspace; calls on one stream are ordered by the stream."""
+        key = self.stream()
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     @staticmethod
     def raise_on_info(info: torch.Tensor, what: str, per_item: int = 1):
@@ -285,9 +289,11 @@ class Engine:
         return max(1, min(want, cap))
 
     def aux_stream(self):
-        if self._aux is None:
-            self._aux = torch.cuda.Stream(device=self.device)
-        return self._aux
+        """Second stream of the fused call (the tiled form of K2 runs as two half-batches), one per calling stream."""
+        key = self.stream()
+        if key not in self._aux:
+            self._aux[key] = torch.cuda.Stream(device=self.device)
+        return self._aux[key]
 
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,

@@ -74,9 +74,9 @@ def _order(signals, max_model_order, optimal_model_order, crit_type, plot, comme
 
 
 # ----------------------------------------------------------------------------- public API
-def lag_covariances(x, p):
+def lag_covariances(x, p, engine: Engine | None = None):
     """R_l = X[:, :n-l] X[:, l:].T / n, l = 0..p, trial-averaged; (p+1, m, m).  (mtmvar.py:57-59,72-73)"""
-    eng = default_engine()
+    eng = engine or default_engine()
     R, m, _ = _lagcov_mean(x, int(p), eng)
     return R[0, :, :m, :m].cpu().numpy()
 
@@ -122,14 +122,14 @@ def mvar_transfer_function(ar_coeffs, freqs, fs):
     return H, A
 
 
-def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra")):
+def mvar_analysis(signals, freqs, fs, model_order, want=("ffdtf", "spectra"), engine: Engine | None = None):
     """One fit, several products: any of 'ar', 'V', 'H', 'A', 'dtf', 'ffdtf', 'spectra', 'pcoh', 'ddtf', 'gpdc'
-    as a dict.
+    as a dict.  `engine`: run on this Engine instead of the process-wide default (extra keyword, not in the reference).
 
     Not in the reference (which refits for every product, mtmvar.py:165-284); this is what the pipeline
     mirror uses so that ffDTF and spectra share the lag covariances, the solve and the inverses.
     """
-    eng = default_engine()
+    eng = engine or default_engine()
     p = int(model_order)
     ar, V, _, m, _ = _fit(signals, p, eng)
     tw = eng.twiddles(freqs, fs, p)
@@ -219,7 +219,7 @@ def gen_partial_directed_coherence(signals, freqs, fs, max_model_order=20, optim
     return mvar_analysis(signals, np.asarray(freqs), fs, p, want=("gpdc",))["gpdc"]
 
 
-def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):
+def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False, engine: Engine | None = None):
     """AIC / HQ / SC over p = 1..max_model_order (mtmvar.py:551-601): (crit, p_range, optimal_order)."""
     data = np.asarray(data, dtype=np.float64)
     n_channels, n_samples = data.shape                       # 2-D only, like the reference
@@ -232,7 +232,7 @@ def mvar_criterion(data, max_model_order, crit_type='AIC', plot=False):
         pen = np.log(n_samples) * model_order_range * n_channels ** 2 / n_samples
     else:
         raise ValueError("Invalid criterion type. Choose from 'AIC', 'HQ', 'SC'.")
-    eng = default_engine()
+    eng = engine or default_engine()
     _, _, logdet, _, _ = _fit(data, int(max_model_order), eng, want_logdet=True)
     crit = logdet[0].cpu().numpy() + pen
     best = int(np.argmin(crit))                     # first minimum, like the reference's argmin (Q7)

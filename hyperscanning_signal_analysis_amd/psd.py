@@ -32,9 +32,9 @@ def _tapers(n_times: int, half_nbw: float):
     return np.ascontiguousarray(tapers[idx]), np.sqrt(eig[idx])
 
 
-def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30):
+def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30, engine=None):
     """(freqs, psd): psd (n_channels, n_freqs) on fmin <= f <= fmax, like src/psd.py:7-33."""
-    eng = default_engine()
+    eng = engine or default_engine()
     x = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
     if x.ndim != 2:
         raise ValueError("data must have shape (n_channels, n_times)")

@@ -95,3 +95,23 @@ def test_bad_window_descriptors_are_refused_before_any_launch():
     ]:
         with pytest.raises(ValueError, match=msg):
             validate_items(x, bad_rec, bad_st, n, p)
+
+
+def test_host_sanitizer_build_of_the_c_abi():
+    """the host code of the C-ABI shim (argument checks, workspace layouts, launch sequencing) built
+    with AddressSanitizer + UBSan (`make -C csrc asan`; device code untouched) and driven through every entry
+    point's refusal paths in a child process under the ASan runtime.  CPU only; never on the GPU box."""
+    import glob
+    asan_lib = os.path.join(PKG, "libhypermvar_asan.so")
+    if not os.path.exists(asan_lib):
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "asan", "-j", "8"], check=True, capture_output=True)
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    assert rt, "ASan runtime of the ROCm clang not found"
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env.pop("HYPERMVAR_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py")], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "asan driver ok" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr
