@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 from hyperscanning_signal_analysis_amd import _lib as hlib                  # noqa: E402
 from hyperscanning_signal_analysis_amd import distributed as hdist          # noqa: E402
 from hyperscanning_signal_analysis_amd.engine import Engine                 # noqa: E402
-from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions  # noqa: E402
+from hyperscanning_signal_analysis_amd.sliding import regular_grid, window_items, window_positions  # noqa: E402
 from hyperscanning_signal_analysis_amd.synthetic import NORTHSTAR, northstar_freqs, synthetic_var_dyad  # noqa: E402
 
 # Algorithmic flops per window; K3 = A(f) build + complex inverses + |H|^2 + row sums
@@ -111,6 +111,11 @@ def main():
                     help="ffDTF normalisation as a separate pass (K4) instead of inside K3 (A/B measurements)")
     ap.add_argument("--yw-one-launch", action="store_true",
                     help="K2 as one workgroup per window in one launch instead of the chain of tile launches (A/B)")
+    ap.add_argument("--direct-lagcov", action="store_true",
+                    help="K1 sums every window from its own samples instead of sharing the 50 %% overlap (A/B)")
+    ap.add_argument("--with-spectra", action="store_true",
+                    help="side measurement: ffDTF AND multivariate spectra S = H V H^T of every window from one fit "
+                         "(what the reference's orchestrators always compute together); reported as `with_spectra`")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code path "
                          "with several ranks on ONE GPU)")
@@ -156,10 +161,12 @@ def main():
     two_streams = not args.single_stream
     flags = (hlib.FLAG_UNFUSED_NORM if args.unfused_norm else 0) | (hlib.FLAG_YW_ONE_LAUNCH if args.yw_one_launch else 0)
 
+    grid = None if args.direct_lagcov else regular_grid(positions, w, p)     # (hop, first, n_win): K1 shares the overlap
+
     def step(k3_events=None, check=False, dst=None, fl=None):
         return eng.sliding_ffdtf(x, item_rec, item_start, w, p, fdev, fs, out=out if dst is None else dst, check=check,
                                  chunk=chunk, k3_events=k3_events, overlap=two_streams,
-                                 flags=flags if fl is None else fl, return_ar=check)
+                                 flags=flags if fl is None else fl, return_ar=check, grid=grid)
 
     def barrier():
         if world > 1:
@@ -200,7 +207,7 @@ def main():
         checks["max_row_sum_error"] = rowsum_err
         other = eng.empty(n_windows, m, m, F)                           # the other normalisation path, dyad 0
         eng.sliding_ffdtf(x[:1], item_rec[:n_windows], item_start[:n_windows], w, p, fdev, fs, out=other, check=False,
-                          chunk=chunk, overlap=two_streams, flags=flags ^ hlib.FLAG_UNFUSED_NORM)
+                          chunk=chunk, overlap=two_streams, flags=flags ^ hlib.FLAG_UNFUSED_NORM, grid=grid)
         checks["fused_equals_separate_normalisation_bitwise"] = bool(torch.equal(other, out[:n_windows]))
         assert checks["fused_equals_separate_normalisation_bitwise"], "in-kernel and separate normalisation differ"
         del other
@@ -211,6 +218,29 @@ def main():
             got = out[kw].cpu().numpy()
             checks["oracle_window_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
             assert checks["oracle_window_rel_err"] < 1e-9
+
+    spectra_res = None
+    if args.with_spectra:                    # ffDTF + spectra of dyad 0 from one fit, after the headline measurement
+        nsp = min(n_windows, 256)
+        S_out = eng.empty(nsp, m, m, F, 2)
+        ff_sp = eng.empty(nsp, m, m, F)
+
+        def sp_step():
+            return eng.sliding_ffdtf_spectra(x[:1], item_rec[:nsp], item_start[:nsp], w, p, fdev, fs, chunk=64,
+                                             check=False, out_ff=ff_sp, out_S=S_out)
+        sp_step()
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(3):
+            sp_step()
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - ts0) / 3
+        spectra_res = {"windows_per_s": nsp / ts, "ms_per_window": ts / nsp * 1e3, "windows": nsp,
+                       # (bitwise when K1 is the same: this path sums every window from its own samples)
+                       "ffdtf_max_rel_diff_to_headline_path": float((ff_sp - out[:nsp]).abs().max() / out[:nsp].abs().max()),
+                       "flop_per_window": FLOP_WINDOW + 1073.7e6,
+                       "tflops": (FLOP_WINDOW + 1073.7e6) * nsp / ts / 1e12}
+        del S_out, ff_sp
 
     if rank == 0:
         k3_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -234,6 +264,8 @@ def main():
                                    "(%d windows per dyad), MVAR p=8, 256 freqs 0.5-128 Hz"
                                    % (2 if D == 1 else 3, D, args.minutes, n_windows),
                        "windows_per_step_per_gpu": n_items, "dyads_per_gpu": D,
+                       "k1": "every window from its own samples" if grid is None else
+                             "hop blocks summed once, shared by the overlapping windows (hop %d)" % grid[0],
                        "k2": "one workgroup per window, one launch" if args.yw_one_launch
                              else "tile launches on %d stream(s)" % (2 if two_streams else 1),
                        "normalisation": "separate K4 pass" if args.unfused_norm else "inside K3 (rows of window w by "
@@ -251,6 +283,8 @@ def main():
             "path_frac_of_peak": FLOP_WINDOW * value / world / 1e12 / PEAK_F64_TFLOPS,
             "checks_after_timed_region": checks,
         }
+        if spectra_res is not None:
+            res["with_spectra"] = spectra_res
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(x_hosts[0], positions, w, p, freqs, fs)
         elif not args.no_cpu_baseline:

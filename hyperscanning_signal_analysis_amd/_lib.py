@@ -20,6 +20,9 @@ SIGNATURES = {
     "hmv_yw_workspace_doubles": (c_int64, [c_int, c_int]),
     "hmv_lagcov_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                c_void_p, c_void_p]),
+    "hmv_lagcov_regular_workspace_doubles": (c_int64, [c_int64, c_int, c_int, c_int64, c_int]),
+    "hmv_lagcov_regular_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
     "hmv_yw_solve_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int64, c_void_p]),
     "hmv_twiddles_f64": (c_int, [c_void_p, c_int, c_double, c_int, c_void_p, c_void_p]),
@@ -46,14 +49,15 @@ SIGNATURES = {
                                  c_double, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hmv_sliding_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_int64, c_int64, c_double, c_int64, c_void_p, c_void_p,
-                                      c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_int64, c_int64, c_double, c_int64, c_int64, c_int64, c_int64,
+                                      c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 # option bits of the fused entry points (include/hypermvar.h)
 FLAG_UNFUSED_NORM = 1
 FLAG_YW_TILED = 2
 FLAG_YW_ONE_LAUNCH = 4
+FLAG_DIRECT_LAGCOV = 8
 
 
 _lib = None

@@ -43,12 +43,43 @@ int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_lagcov_f64: model order must be in 1..32");
   if (n <= p) return fail(-3, "hmv_lagcov_f64: window shorter than the model order");
   if (!x || !item_rec || !item_start || !R || n_items < 0) return fail(-4, "hmv_lagcov_f64: null pointer");
-  hmv::LagcovArgs a;
+  hmv::LagcovArgs a{};
   a.x = x; a.rec_stride = rec_stride; a.ld = ld;
   a.item_rec = reinterpret_cast<const long long*>(item_rec);
   a.item_start = reinterpret_cast<const long long*>(item_start);
   a.n_items = n_items; a.m = m; a.n = n; a.p = p; a.R = R;
   return hmv::launch_lagcov(a, mp, S(stream));
+}
+
+int64_t hmv_lagcov_regular_workspace_doubles(int64_t n_win, int m, int n, int64_t hop, int p) {
+  const int mp = pad_of(m);
+  if (mp < 0 || n_win < 0 || hop < 1 || n < 1 || n % hop != 0 || p < 0) return -1;
+  return (n_win + n / hop - 1) * (int64_t)(p + 1) * mp * mp;
+}
+
+int hmv_lagcov_regular_f64(const double* x, int64_t ld, int64_t T, int64_t first, int64_t hop, int64_t n_win, int m,
+                           int n, int p, double* R, double* workspace, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_lagcov_regular_f64: channel count must be in 1..64");
+  if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_lagcov_regular_f64: model order must be in 1..32");
+  if (n <= p) return fail(-3, "hmv_lagcov_regular_f64: window shorter than the model order");
+  if (!x || !R || !workspace || n_win < 0) return fail(-4, "hmv_lagcov_regular_f64: null pointer");
+  if (hop < 1 || n % hop != 0 || hop <= p)
+    return fail(-5, "hmv_lagcov_regular_f64: the window must be a whole number of hops and a hop longer than the order");
+  if (first < 0 || ld < T || (n_win > 0 && first + (n_win - 1) * hop + n > T))
+    return fail(-6, "hmv_lagcov_regular_f64: windows do not lie inside the recording");
+  if (n_win == 0) return 0;
+  const int k = (int)(n / hop);
+  hmv::LagcovArgs a{};
+  a.x = x; a.rec_stride = 0; a.ld = ld; a.item_rec = nullptr; a.item_start = nullptr;
+  a.n_items = n_win + k - 1; a.m = m; a.n = (int)hop; a.p = p; a.R = workspace;
+  a.blocks = 1; a.blk_first = first; a.blk_T = T;
+  int rc = hmv::launch_lagcov(a, mp, S(stream));
+  if (rc) return rc;
+  hmv::LagcombArgs c{};
+  c.Q = workspace; c.x = x; c.ld = ld; c.first = first; c.hop = hop; c.T = T; c.n_win = n_win; c.k = k; c.m = m; c.p = p;
+  c.R = R;
+  return hmv::launch_lagcomb(c, mp, S(stream));
 }
 
 int hmv_yw_solve_f64(const double* R, int64_t n_items, int m, int p, double* ws, double* ar, double* V,
@@ -276,13 +307,14 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
 // ---- fused sliding-window path ----------------------------------------------------------------------
 namespace {
 struct SlidingWs {
-  size_t off_R, off_ws, off_ar, off_V, off_tf, off_den, off_tw, total;
+  size_t off_R, off_Q, off_ws, off_ar, off_V, off_tf, off_den, off_tw, total;
 };
 SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   SlidingWs w;
   size_t o = 0;
   const size_t t = (size_t)mp * mp;
   w.off_R = o;      o += align256(sizeof(double) * chunk * (p + 1) * t);
+  w.off_Q = o;      o += align256(sizeof(double) * (chunk + HMV_MAX_HOPS_PER_WINDOW - 1) * (p + 1) * t);   // hop-block sums
   w.off_ws = o;     o += align256(sizeof(double) * chunk * hmv::yw_ws_tiles(p) * t);
   w.off_ar = o;     o += align256(sizeof(double) * chunk * t * p);
   w.off_V = o;      o += align256(sizeof(double) * chunk * t);
@@ -320,8 +352,9 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
                           const int64_t* item_start, int64_t n_items, int m, int n, int p,
                           const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
-                          int64_t chunk, double pivot_tau, int64_t flags, void* ev_k3_start, void* ev_k3_stop,
-                          void* stream, void* aux_stream) {
+                          int64_t chunk, double pivot_tau, int64_t flags, int64_t grid_hop, int64_t grid_first,
+                          int64_t grid_nwin, int64_t grid_T, void* ev_k3_start, void* ev_k3_stop, void* stream,
+                          void* aux_stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
@@ -331,6 +364,15 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
   const SlidingWs w = sliding_layout(chunk, mp, p, F);
   if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
+  // Regular grid (the caller vouches: item = rec * grid_nwin + w starts at grid_first + w * grid_hop of recording rec,
+  // recordings are grid_T samples long): K1 sums every hop block once and assembles the windows from the blocks.
+  bool regular = grid_hop > 0 && !(flags & HMV_FLAG_DIRECT_LAGCOV);
+  if (regular) {
+    if (grid_nwin < 1 || grid_first < 0 || n_items % grid_nwin != 0 || grid_first + (grid_nwin - 1) * grid_hop + n > grid_T ||
+        ld < grid_T)
+      return fail(-9, "hmv_sliding_ffdtf_f64: inconsistent regular window grid");
+    regular = (n % grid_hop == 0) && (n / grid_hop >= 2) && (n / grid_hop <= HMV_MAX_HOPS_PER_WINDOW) && grid_hop > p;
+  }
   // Second stream (HMV_FLAG_YW_TILED only): the tile-per-workgroup form of K2 is a chain of ~25 launches of at
   // most a few workgroups per window that cannot fill the chip; it runs as two half-batches, one per stream,
   // whose launches interleave on the device (fork after K1, join before K3).  The default one-launch form of K2
@@ -348,6 +390,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   const int64_t n_chunks = (n_items + chunk - 1) / chunk;
   char* base = static_cast<char*>(workspace);
   double* R = reinterpret_cast<double*>(base + w.off_R);
+  double* Qb = reinterpret_cast<double*>(base + w.off_Q);
   double* ws = reinterpret_cast<double*>(base + w.off_ws);
   double* ar = reinterpret_cast<double*>(base + w.off_ar);
   double* V = reinterpret_cast<double*>(base + w.off_V);
@@ -362,7 +405,18 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     const int64_t c = (n_items - i0 < chunk) ? (n_items - i0) : chunk;
     double* ar_c = ar_out ? ar_out + (size_t)i0 * t * p : ar;
     double* V_c = V_out ? V_out + (size_t)i0 * t : V;
-    rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, st0);
+    if (regular) {
+      // items i0 .. i0+c-1 as runs of consecutive windows of one recording each (item = rec * grid_nwin + w)
+      for (int64_t it = i0; it < i0 + c && rc == 0;) {
+        const int64_t rec = it / grid_nwin, w0 = it - rec * grid_nwin;
+        const int64_t run = ((grid_nwin - w0) < (i0 + c - it)) ? (grid_nwin - w0) : (i0 + c - it);
+        rc = hmv_lagcov_regular_f64(x + rec * rec_stride, ld, grid_T, grid_first + w0 * grid_hop, grid_hop, run, m, n, p,
+                                    R + (size_t)(it - i0) * (p + 1) * t, Qb, st0);
+        it += run;
+      }
+    } else {
+      rc = hmv_lagcov_f64(x, rec_stride, ld, item_rec + i0, item_start + i0, c, m, n, p, R, st0);
+    }
     if (rc) break;
     // the tiled form of K2 (asked for, or chosen for a large 64-channel chunk) as two half-batches
     const bool tiled = (flags & HMV_FLAG_YW_TILED) || (!(flags & HMV_FLAG_YW_ONE_LAUNCH) && mp == 64 && c >= 128);

@@ -15,8 +15,23 @@ struct LagcovArgs {
   long long n_items;
   int m, n, p;              // channels, window length, model order
   double* R;                // [n_items][p+1][MP][MP]
+  // hop-block mode (blocks != 0): item b is the block of `n` (= hop) samples starting at blk_first + b * n of ONE
+  // recording x (item_rec / item_start unused); lagged partners beyond the block are read up to the end of the
+  // recording (blk_T samples), the sums are left unscaled and the padding is left zero: R = partial sums Q_l(b).
+  int blocks;
+  long long blk_first, blk_T;
 };
 int launch_lagcov(const LagcovArgs& a, int m_pad, hipStream_t st);
+// windows of k consecutive hop blocks from the block sums: R[w][l] = (sum_{j<k} Q[w+j][l] - C_l(w)) / n
+struct LagcombArgs {
+  const double* Q;          // [n_win + k - 1][p+1][MP][MP]
+  const double* x;          // the recording: [m][ld]
+  long long ld, first, hop, T;
+  long long n_win;
+  int k, m, p;
+  double* R;                // [n_win][p+1][MP][MP]
+};
+int launch_lagcomb(const LagcombArgs& a, int m_pad, hipStream_t st);
 
 // ---- K2 Yule-Walker solve (block LDL^T of the block-Toeplitz normal equations) ------------------
 struct YwArgs {

@@ -129,6 +129,24 @@ class Engine:
         _lib.check(rc, "hmv_lagcov_f64")
         return R
 
+    def lagcov_regular(self, x: torch.Tensor, first: int, hop: int, n_win: int, n: int, p: int):
+        """x: (m, T) ONE recording; windows first + w*hop .. + n (n = k hops) -> R (n_win, p+1, MP, MP) with the hop
+        blocks summed once and shared by the overlapping windows (`hmv_lagcov_regular_f64`)."""
+        assert x.dim() == 2 and x.dtype == torch.float64 and x.is_cuda
+        x = x if x.stride(1) == 1 else x.contiguous()
+        m, T = x.shape
+        mp = self.pad(m)
+        nws = int(self.lib.hmv_lagcov_regular_workspace_doubles(n_win, m, int(n), int(hop), int(p)))
+        if nws < 0:
+            raise ValueError("the window must be a whole number of hops")
+        ws = self.empty(max(nws, 1))
+        R = self.empty(n_win, p + 1, mp, mp)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_lagcov_regular_f64(x.data_ptr(), x.stride(0), T, int(first), int(hop), int(n_win), m, int(n),
+                                                 int(p), R.data_ptr(), ws.data_ptr(), self.stream())
+        _lib.check(rc, "hmv_lagcov_regular_f64")
+        return R
+
     def trial_mean(self, R: torch.Tensor, m: int):
         """(trials, p+1, MP, MP) -> (1, p+1, MP, MP): count_corr's average over trials (mtmvar.py:78-85)."""
         trials, p1, mp, _ = R.shape
@@ -298,7 +316,7 @@ class Engine:
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
                       check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True,
-                      flags: int = 0):
+                      flags: int = 0, grid=None):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
         check: True raises numpy.linalg.LinAlgError("Singular matrix") if ANY window failed, like the reference's
@@ -307,6 +325,10 @@ class Engine:
         overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the
         chip, then runs as two half-batches that interleave on the device (see include/hypermvar.h).
         flags: option bits of include/hypermvar.h (`_lib.FLAG_*`); 0 = the fast defaults.
+        grid: (hop, first, n_win) when the items are a REGULAR grid -- item = rec * n_win + w is the window starting
+        at first + w * hop of recording rec (`sliding.regular_grid` derives it from the start positions): K1 then sums
+        every hop block once and shares it between the overlapping windows (half its flops at 50 % overlap; equal to
+        the direct form to rounding, not bitwise -- `_lib.FLAG_DIRECT_LAGCOV` keeps the direct form).
         k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
         have been recorded once) which the library records around the dominant kernel.
         """
@@ -333,12 +355,15 @@ class Engine:
         V = self.empty(n_items, mp, mp) if return_ar else None
         info_yw = self.empty(n_items, dtype=torch.int32)
         info_tf = self.empty(n_items * F, dtype=torch.int32)
+        g_hop, g_first, g_nwin = (int(v) for v in grid) if grid is not None else (0, 0, 0)
+        if grid is not None and (g_nwin < 1 or n_items % g_nwin or g_hop < 1):
+            raise ValueError("grid = (hop, first, n_win) does not match the number of items")
         with torch.cuda.device(self.device):
             rc = self.lib.hmv_sliding_ffdtf_f64(
                 x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
                 m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
                 info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
-                k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
+                g_hop, g_first, g_nwin, T, k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
         _lib.check(rc, "hmv_sliding_ffdtf_f64")
         if check == "nan":          # keep the good windows, NaN-fill the ones whose fit or inverse was singular
             badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
@@ -350,6 +375,48 @@ class Engine:
         if return_ar:
             return out, ar, V, (info_yw, info_tf)
         return out
+
+
+    # ------------------------------------------------------------------ ffDTF + spectra from ONE fit
+    def sliding_ffdtf_spectra(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
+                              freqs, fs: float, chunk: int = 64, check: bool = True, out_ff=None, out_S=None):
+        """Both products the reference's orchestrators always compute together (full_freq_dtf + multivariate_spectra,
+        /root/reference/src/eeg_alpha_ibi_ffdtf.py:592-604, src/mtmvar.py:1100-1113) from ONE fit and ONE set of
+        inverses per window: K1 -> K2 -> K3 (|H|^2 and H) -> K4 -> K5 -> layout transpose, `chunk` windows at a time
+        (H and S are 16.8 MB per window each).  Returns (ffdtf (items, m, m, F) real, S (items, m, m, F) complex)."""
+        assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
+        x = x if x.stride(2) == 1 else x.contiguous()
+        n_rec, m, T = x.shape
+        self.check_items(x, item_rec, item_start, n, p)
+        n_items = int(item_rec.numel())
+        f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
+        F = int(f.numel())
+        tw = self.empty(F, p, 2)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.hmv_twiddles_f64(f.data_ptr(), F, float(fs), p, tw.data_ptr(), self.stream()),
+                       "hmv_twiddles_f64")
+        ff = self.empty(n_items, m, m, F) if out_ff is None else out_ff
+        S = self.empty(n_items, m, m, F, 2) if out_S is None else out_S
+        infos = []
+        for i0 in range(0, n_items, chunk):
+            sl = slice(i0, min(n_items, i0 + chunk))
+            R = self.lagcov(x, item_rec[sl], item_start[sl], n, p)
+            ar, V, _, info_yw = self.yw_solve(R, m)
+            t = self.transfer(ar, m, tw, want_P=True, want_H=True)
+            c = ar.shape[0]
+            den = self.empty(c, t["P"].shape[2])
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.hmv_ffdtf_norm_f64(t["P"].data_ptr(), t["rowsum"].data_ptr(), den.data_ptr(),
+                                                       ff[sl].data_ptr(), c, F, m, 1, self.stream()), "hmv_ffdtf_norm_f64")
+                Sk = self.spectra(t["H"], V, m)
+                _lib.check(self.lib.hmv_transpose_c128(Sk.data_ptr(), S[sl].data_ptr(), c, F, m, self.stream()),
+                           "hmv_transpose_c128")
+            infos.append((info_yw, t["info"]))
+        if check:
+            for info_yw, info_tf in infos:
+                self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
+                self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
+        return ff, torch.view_as_complex(S)
 
 
 _default = None

@@ -35,7 +35,7 @@ import numpy as np
 from . import distributed as hdist
 from .eeg_io import filter_eeg
 from .engine import default_engine
-from .sliding import window_items, window_positions
+from .sliding import regular_grid, window_items, window_positions
 
 __all__ = ["discover_dyads", "decode_events", "segment_block", "run", "xarray_reader"]
 
@@ -168,7 +168,8 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                     f = np.asarray(freqs if freqs is not None else np.arange(0.5, min(fs / 2.0, 128.0) + 1e-9, 0.5))
                     xd = eng.to_device(block[None])
                     rec_i, st_i = window_items(1, pos, eng.device)
-                    ff = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="nan")
+                    ff = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="nan",
+                                           grid=regular_grid(pos, W, int(model_order)))
                     lo, hi = hdist.band_bins(f, bands)
                     key = f"{task}/{name}"
                     result[f"{key}/ffdtf_bands"] = eng.band_sums(ff, lo, hi).cpu().numpy()

@@ -12,7 +12,7 @@ import torch
 
 from .engine import Engine, default_engine
 
-__all__ = ["window_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf_device", "window_items"]
+__all__ = ["window_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf_device", "window_items", "regular_grid"]
 
 
 def window_positions(T: int, n_windows: int = 3, window_size=None):
@@ -60,14 +60,31 @@ def window_items(n_rec: int, positions, device):
     return item_rec, item_start
 
 
+def regular_grid(positions, window_size: int, p: int):
+    """(hop, first, n_win) if the start positions are an arithmetic progression whose step divides the window into
+    2..8 whole hops longer than the model order -- the case in which K1 can share the overlap between windows
+    (`Engine.sliding_ffdtf(grid=...)`) -- else None."""
+    pos = np.asarray(positions, dtype=np.int64)
+    if len(pos) < 2:
+        return None
+    hop = int(pos[1] - pos[0])
+    if hop <= int(p) or hop < 1 or not np.array_equal(np.diff(pos), np.full(len(pos) - 1, hop)):
+        return None
+    if window_size % hop != 0 or not 2 <= window_size // hop <= 8:
+        return None
+    return hop, int(pos[0]), len(pos)
+
+
 def sliding_ffdtf_device(x: torch.Tensor, window_size: int, n_windows: int, p: int, freqs, fs: float,
-                         engine: Engine | None = None, out: torch.Tensor | None = None, check: bool = True):
+                         engine: Engine | None = None, out: torch.Tensor | None = None, check: bool = True,
+                         share_overlap: bool = True):
     """x: device tensor (n_rec, m, T) -> device tensor (n_rec, n_windows, m, m, F).  No host copies."""
     eng = engine or default_engine()
     n_rec, m, T = x.shape
     positions, w = window_positions(T, n_windows, window_size)
     item_rec, item_start = window_items(n_rec, positions, eng.device)
-    ff = eng.sliding_ffdtf(x, item_rec, item_start, w, p, freqs, fs, out=out, check=check)
+    ff = eng.sliding_ffdtf(x, item_rec, item_start, w, p, freqs, fs, out=out, check=check,
+                           grid=regular_grid(positions, w, p) if share_overlap else None)
     return ff.view(n_rec, len(positions), m, m, -1)
 
 

@@ -47,6 +47,18 @@ int hmv_lagcov_f64(const double* x, int64_t rec_stride, int64_t ld,
                    const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
                    int m, int n, int p, double* R, void* stream);
 
+/* K1 for a REGULAR grid of overlapping windows of one recording: window w covers samples first + w*hop .. + n with
+ * n a whole number k of hops (50 % overlap: k = 2).  Every product x_i[t] x_j[t+l] then belongs to up to k windows;
+ * the hop blocks are summed once and the windows assembled from the block sums (minus the l products per lag that
+ * reach past a window's end): half the flops of hmv_lagcov_f64 at 50 % overlap.  Same estimator (count_corr,
+ * src/mtmvar.py:57-59, 72-73: biased 1/n, no demeaning) with the sums associated differently -- equal to
+ * hmv_lagcov_f64 to rounding (~1e-16 relative), not bitwise.  x: [m][ld] (ONE recording of T samples), R:
+ * [n_win][p+1][MP][MP], workspace: hmv_lagcov_regular_workspace_doubles(n_win, m, n, hop, p) doubles. */
+#define HMV_MAX_HOPS_PER_WINDOW 8
+int64_t hmv_lagcov_regular_workspace_doubles(int64_t n_win, int m, int n, int64_t hop, int p);
+int hmv_lagcov_regular_f64(const double* x, int64_t ld, int64_t T, int64_t first, int64_t hop, int64_t n_win,
+                           int m, int n, int p, double* R, double* workspace, void* stream);
+
 /* K2.  Yule-Walker solve.  Replaces ar_coeff (src/mtmvar.py:90-123).
  * ar: [item][MP][MP][p] with ar[i][j][k] multiplying x_j(t-k-1) into x_i(t) (lag fastest: the
  * reference's own (m, m, p) layout when m == MP); V: [item][MP][MP] residual covariance.
@@ -131,6 +143,8 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
 
 /* Option bits of the fused entry points (`flags`).  0 = the fast defaults. */
 #define HMV_FLAG_UNFUSED_NORM 1   /* ffDTF normalisation as a separate pass over |H|^2 (K4) instead of inside K3 */
+#define HMV_FLAG_DIRECT_LAGCOV 8   /* K1 sums every window from its own samples even on a regular grid (results then do
+                                     not depend on how the windows are laid out: bit-identical across grids) */
 #define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in ~50 launches, and                          */
 #define HMV_FLAG_YW_ONE_LAUNCH 4  /* K2 as one workgroup per window in one launch: same tile products in the same
                                      order, same bits.  Neither flag: one launch, except for large 64-channel
@@ -157,6 +171,10 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].
  * ar_out / V_out (optional): [n_items][MP][MP][p] / [n_items][MP][MP].
  * info_yw: [n_items], info_tf: [n_items*F].  workspace: hmv_sliding_workspace_bytes(chunk, m, p, F) bytes.
+ * grid_hop > 0 declares a REGULAR window grid and lets K1 share the overlap (hmv_lagcov_regular_f64): the caller
+ * vouches that item = rec * grid_nwin + w is the window starting at grid_first + w * grid_hop of recording rec
+ * (item_rec / item_start must say the same; they are still what every other stage and the direct form read) and
+ * that recordings are grid_T samples long.  Taken when n is 2..8 whole hops; grid_hop = 0: arbitrary windows.
  * ev_k3_start / ev_k3_stop (optional hipEvent_t, NULL to skip) are recorded on `stream` right before
  * and after the LAST chunk's K3 launch, so a caller can time the dominant kernel inside its own timed
  * region without an extra synchronisation.
@@ -171,8 +189,9 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           double* ffdtf, double* ar_out, double* V_out,
                           int32_t* info_yw, int32_t* info_tf,
                           void* workspace, int64_t workspace_bytes, int64_t chunk,
-                          double pivot_tau, int64_t flags, void* ev_k3_start, void* ev_k3_stop,
-                          void* stream, void* aux_stream);
+                          double pivot_tau, int64_t flags,
+                          int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T,
+                          void* ev_k3_start, void* ev_k3_stop, void* stream, void* aux_stream);
 
 #ifdef __cplusplus
 }

@@ -19,12 +19,18 @@ for m, p in ((64, 8), (3, 1), (65, 8), (64, 0), (64, 33)):
 for args in ((1, 64, 8, 256), (599, 64, 8, 256), (0, 64, 8, 256), (5, 65, 8, 256), (5, 64, 40, 256), (5, 4, 5, 0)):
     lib.hmv_sliding_workspace_bytes(*args); lib.hmv_tf_ffdtf_workspace_bytes(*args); n += 2
 lib.hmv_tf_workspace_doubles(10, 64, 8); lib.hmv_tf_workspace_doubles(-1, 64, 8); lib.hmv_psd_workspace_bytes(4, 1000, 7)
+lib.hmv_lagcov_regular_workspace_doubles(599, 64, 1000, 500, 8); lib.hmv_lagcov_regular_workspace_doubles(5, 64, 1000, 300, 8)
 lib.hmv_psd_workspace_bytes(0, 1, 0)
 bad = [
     lib.hmv_lagcov_f64(D, 0, 0, D, D, 1, 65, 100, 4, D, 0),
     lib.hmv_lagcov_f64(D, 0, 0, D, D, 1, 4, 100, 40, D, 0),
     lib.hmv_lagcov_f64(D, 0, 0, D, D, 1, 4, 3, 4, D, 0),
     lib.hmv_lagcov_f64(0, 0, 0, D, D, 1, 4, 100, 4, D, 0),
+    lib.hmv_lagcov_regular_f64(D, 1000, 1000, 0, 500, 1, 99, 1000, 4, D, D, 0),
+    lib.hmv_lagcov_regular_f64(D, 1000, 1000, 0, 300, 1, 4, 1000, 4, D, D, 0),
+    lib.hmv_lagcov_regular_f64(D, 1000, 1000, 600, 500, 1, 4, 1000, 4, D, D, 0),
+    lib.hmv_lagcov_regular_f64(D, 1000, 1000, 0, 500, 1, 4, 1000, 4, D, 0, 0),
+    lib.hmv_sliding_ffdtf_f64(D, 0, 1000, D, D, 3, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 50, 0, 2, 1000, 0, 0, 0, 0),
     lib.hmv_yw_solve_f64(D, 1, 70, 4, D, D, D, 0, D, 0, 0),
     lib.hmv_yw_solve_f64(D, 1, 4, 0, D, D, D, 0, D, 0, 0),
     lib.hmv_yw_solve_f64(0, 1, 4, 4, D, D, D, 0, D, 0, 0),
@@ -49,12 +55,12 @@ bad = [
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 900, D, D, 3, 1, 100, D, D, 1 << 30, 4, 0),
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 1000, D, D, 3, 1, 600, D, D, 1 << 30, 4, 0),
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 1000, D, D, 3, 1, 100, D, D, 8, 4, 0),
-    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 65, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0),
-    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 64, 3, 1.0, 0, 0, 0, 0, 0),
-    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, 0, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 65, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 64, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, 0, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
 ]
 assert all(rc < 0 for rc in bad), bad
-assert lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0) == 0
+assert lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == 0
 assert lib.hmv_tf_ffdtf_f64(D, 0, 4, 2, D, 4, D, D, D, 1.0, D, 0, 0, 0, 0, 0) == 0        # empty batches: nothing to do
 assert len(lib.hmv_last_error()) > 0
 print(f"asan driver ok: {n + len(bad)} calls")

@@ -363,10 +363,13 @@ def test_northstar_full_size_properties():
     # determinism: a second run is bit-identical (fixed reduction orders everywhere)
     ff2 = sliding_ffdtf_device(xd, w, nw, p, freqs, fs, eng)[0]
     assert torch.equal(ff, ff2)
-    # batching invariance: window k computed alone equals window k of the batch, bit for bit
+    # batching invariance: window k computed alone equals window k of the batch, bit for bit, when K1 sums every
+    # window from its own samples (the default shares the 50 % overlap between windows: equal to rounding)
     k = 17
     alone = sliding_ffdtf_device(xd[:, :, 500 * k:500 * k + w].contiguous(), w, 1, p, freqs, fs, eng)[0, 0]
-    assert torch.equal(alone, ff[k])
+    direct = sliding_ffdtf_device(xd, w, nw, p, freqs, fs, eng, share_overlap=False)[0]
+    assert torch.equal(alone, direct[k])
+    assert float((direct - ff).abs().max() / direct.abs().max()) < 1e-11
     for k in (0, 29, nw - 1):
         ref = O.full_freq_dtf(x[:, 500 * k:500 * k + w], freqs, fs, p)
         assert_parity(ff[k].cpu().numpy(), ref)
@@ -446,6 +449,33 @@ def test_yule_walker_one_launch_equals_tiled_launch_chain(m, n, p):
     assert_parity(a1[5, :m, :m].cpu().numpy(), aro, 1e-8); assert_parity(v1[5, :m, :m].cpu().numpy(), Vo, 1e-8)
 
 
+@pytest.mark.parametrize("m,n,hop,p,T,first", [(64, 1000, 500, 8, 6000, 0), (64, 1000, 250, 8, 4250, 250), (19, 90, 45, 3, 1000, 10),
+                                             (5, 66, 33, 2, 400, 4), (33, 512, 64, 6, 2048, 0), (48, 300, 100, 4, 1500, 200)])
+def test_lag_covariances_from_shared_hop_blocks(m, n, hop, p, T, first):
+    """K1 on a regular grid (hop blocks summed once, windows = k blocks minus the products that reach past the window
+    end) against K1 window by window: same estimator (biased 1/n, not demeaned), sums associated differently --
+    equal to rounding; the last window may end exactly at the end of the recording; padded channels keep the
+    identity block; hops that are not a multiple of the 4-sample MFMA step are masked correctly."""
+    eng = default_engine()
+    x = synthetic_var_dyad(31, m=m, p=min(p, 4), T=T, burn=200)
+    xd = eng.to_device(x[None])
+    n_win = (T - first - n) // hop + 1
+    assert first + (n_win - 1) * hop + n <= T
+    st = first + hop * torch.arange(n_win, dtype=torch.int64, device=eng.device)
+    rec = torch.zeros(n_win, dtype=torch.int64, device=eng.device)
+    direct = eng.lagcov(xd, rec, st, n, p)
+    shared = eng.lagcov_regular(xd[0], first, hop, n_win, n, p)
+    assert shared.shape == direct.shape
+    assert float((shared - direct).abs().max() / direct.abs().max()) < 1e-13
+    mp = direct.shape[-1]
+    if mp > m:
+        assert torch.equal(shared[:, 0, m:, m:], torch.eye(mp - m, dtype=torch.float64, device=eng.device).expand(n_win, -1, -1))
+        assert not bool(shared[:, 1:, m:, :].any()) and not bool(shared[:, :, :m, m:].any())
+    assert_parity(shared[n_win - 1, :, :m, :m].cpu().numpy(), O.lag_covariances(x[:, first + (n_win - 1) * hop:][:, :n], p), 1e-12)
+    with pytest.raises(ValueError):
+        eng.lagcov_regular(xd[0], first, hop, n_win + 1 + (T - first - n) // hop, n, p)       # past the recording
+
+
 def test_multi_dyad_batch_matches_single_dyad_runs():
     """Config 3 in miniature: several dyads in one batch (dyad x window items, forced into several chunks)
     give bit-identical results to running each dyad alone -- the property dyad-sharding across GPUs relies on."""
@@ -460,8 +490,16 @@ def test_multi_dyad_batch_matches_single_dyad_runs():
     rec, st = window_items(3, pos, eng.device)
     batch = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, chunk=7).view(3, nw, 64, 64, 32)
     for d in range(3):
-        alone = sliding_ffdtf_device(xd[d:d + 1].contiguous(), w, nw, p, freqs, fs, eng)[0]
+        alone = sliding_ffdtf_device(xd[d:d + 1].contiguous(), w, nw, p, freqs, fs, eng, share_overlap=False)[0]
         assert torch.equal(alone, batch[d])
+    # the same batch on the declared regular grid (K1 shares the overlap; chunks of 7 cut through the recordings)
+    from hyperscanning_signal_analysis_amd.sliding import regular_grid
+    g = regular_grid(pos, w, p)
+    assert g == (500, 0, nw)
+    shared = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, chunk=7, grid=g).view(3, nw, 64, 64, 32)
+    shared1 = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, grid=g).view(3, nw, 64, 64, 32)
+    assert torch.equal(shared, shared1)                               # chunking does not change the block sums
+    assert float((shared - batch).abs().max() / batch.abs().max()) < 1e-11
     ref = O.full_freq_dtf(xs[2][:, 500 * 5:500 * 5 + w], freqs, fs, p)
     assert_parity(batch[2, 5].cpu().numpy(), ref)
 
