@@ -221,12 +221,12 @@ def main():
 
     spectra_res = None
     if args.with_spectra:                    # ffDTF + spectra of dyad 0 from one fit, after the headline measurement
-        nsp = min(n_windows, 256)
+        nsp = n_windows
         S_out = eng.empty(nsp, m, m, F, 2)
         ff_sp = eng.empty(nsp, m, m, F)
 
         def sp_step():
-            return eng.sliding_ffdtf_spectra(x[:1], item_rec[:nsp], item_start[:nsp], w, p, fdev, fs, chunk=64,
+            return eng.sliding_ffdtf_spectra(x[:1], item_rec[:nsp], item_start[:nsp], w, p, fdev, fs, chunk=300,
                                              check=False, out_ff=ff_sp, out_S=S_out)
         sp_step()
         torch.cuda.synchronize()

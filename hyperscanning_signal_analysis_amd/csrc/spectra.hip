@@ -2,49 +2,110 @@
 //
 // Replaces the per-frequency loop of `multivariate_spectra` (/root/reference/src/mtmvar.py:165-201,
 // the product at :199).  One workgroup (4 waves) per (window, frequency): H (complex, from K3) and V
-// (real, from K2) are staged in LDS, T = H V costs two real MP^3 GEMMs, S = T H^T four more, all on
-// v_mfma_f64_4x4x4_4b_f64 with wave w owning row blocks w*NT.. of the output (same tile GEMM as K2).
+// (real, from K2) are staged in LDS a quarter of the k range at a time, T = H V costs two real MP^3 GEMMs,
+// S = T H^T four more, all on v_mfma_f64_4x4x4_4b_f64 with wave w owning row blocks w*NT.. of the output.
 #include "hmv_common.h"
 #include "hmv_kernels.h"
 
 namespace hmv {
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// Operands go through LDS a quarter of the k range at a time (KQ = MP/4 columns): two A-operand images and two
+// B-operand images of MP x KQ doubles (45 KB at 64 channels, so two workgroups share a CU; the round-1 kernel kept
+// four whole MP x MP tiles = 143 KB, one workgroup per CU, nothing in flight behind the MFMAs: 16.3 ms per
+// 599-window dyad against 7.4 ms of pure MFMA time).  The next quarter's global loads are in flight behind the MFMAs
+// of the current one.
+//   stage 1, T = H V:     per quarter  A0/A1 = Re/Im H[:, kq], B0 = V[kq, :]^T        Tr += A0 B0^T, Ti += A1 B0^T
+//   stage 2, S = T H^T:   per quarter  A0/A1 = Tr/Ti[:, kq] (own row strip, from registers), B0/B1 = Re/Im H[:, kq]
+//                                      Sr += A0 B0^T - A1 B1^T,  Si += A0 B1^T + A1 B0^T
+// k ascends 0 .. MP-1 in every sum, as in the round-1 kernel: same bits.
 template <int NT>
-__global__ void __launch_bounds__(256) spectra_kernel(SpecArgs a) {
-  constexpr int MP = 16 * NT, NIW = NT, NJ = NT;
-  constexpr int S = (MP <= 38) ? 38 : 70;
-  constexpr int TILE = MP * MP;
-  __shared__ double L0[MP * S];   // Hr
-  __shared__ double L1[MP * S];   // Hi
-  __shared__ double L2[MP * S];   // V^T, then Tr
-  __shared__ double L3[MP * S];   // Ti
-  const int l = lane_id();
+__global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
+  constexpr int MP = 16 * NT, NIW = NT, NJ = NT, KQ = MP / 4, SQ = KQ + 6, TILE = MP * MP;
+  constexpr int NH = (MP * KQ + 255) / 256;          // complex elements of an H quarter per thread
+  constexpr int NVV = (MP * KQ / 2 + 255) / 256;     // 16-byte loads of a V quarter per thread
+  __shared__ __attribute__((aligned(16))) double A0[MP * SQ], A1[MP * SQ], B0[MP * SQ], B1[MP * SQ];
   const int wv = uni(threadIdx.x >> 6);
-  const int i = l >> 4, cc = l & 15;
   const long long gw = blockIdx.x;                 // item * F + f
   const long long item = gw / a.F;
-  const double2* H = reinterpret_cast<const double2*>(a.H) + (size_t)gw * TILE;
+  const f64x2* H = reinterpret_cast<const f64x2*>(a.H) + (size_t)gw * TILE;
   const double* V = a.V + (size_t)item * TILE;
-
-  for (int idx = threadIdx.x; idx < TILE; idx += 256) {
-    const int row = idx / MP, col = idx - row * MP;
-    const double2 h = H[idx];
-    L0[row * S + col] = h.x;
-    L1[row * S + col] = h.y;
-    L2[col * S + row] = V[idx];
-  }
-  __syncthreads();
-
-  auto gemm_nt = [&](double (&acc)[NIW][NJ], const double* Xs, const double* Ys, bool negate) {
-    const double* xa = Xs + (4 * wv * NT + (l & 3)) * S + (l >> 4);
-    const double* yb = Ys + cc * S + (l >> 4);
-#pragma unroll 2
-    for (int k0 = 0; k0 < MP; k0 += 4) {
+  // thread coordinates re-derived from an opaque lane id per helper (keeps the offsets out of long live ranges)
+  auto lane = [&]() __attribute__((always_inline)) {
+    int lo;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+    return lo;
+  };
+  auto fetch_h = [&](f64x2 (&v)[NH], int kq) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NH; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NH * 256 == MP * KQ || idx < MP * KQ) {
+        const int row = idx / KQ, k = idx - row * KQ;
+        v[r] = H[(size_t)row * MP + kq * KQ + k];
+      }
+    }
+  };
+  auto park_h = [&](double* re, double* im, const f64x2 (&v)[NH]) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NH; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NH * 256 == MP * KQ || idx < MP * KQ) {
+        const int row = idx / KQ, k = idx - row * KQ;
+        re[row * SQ + k] = v[r].x;
+        im[row * SQ + k] = v[r].y;
+      }
+    }
+  };
+  // B0[col][k] = V[kq*KQ + k][col]
+  auto fetch_v = [&](f64x2 (&v)[NVV], int kq) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NVV; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NVV * 256 == MP * KQ / 2 || idx < MP * KQ / 2) {
+        const int k = idx / (MP / 2), c2 = idx - k * (MP / 2);
+        v[r] = *reinterpret_cast<const f64x2*>(V + (size_t)(kq * KQ + k) * MP + 2 * c2);
+      }
+    }
+  };
+  auto park_v = [&](const f64x2 (&v)[NVV]) __attribute__((always_inline)) {
+    const int t0 = lane() + 64 * wv;
+#pragma unroll
+    for (int r = 0; r < NVV; ++r) {
+      const int idx = t0 + 256 * r;
+      if (NVV * 256 == MP * KQ / 2 || idx < MP * KQ / 2) {
+        const int k = idx / (MP / 2), c2 = idx - k * (MP / 2);
+        B0[(2 * c2) * SQ + k] = v[r].x;
+        B0[(2 * c2 + 1) * SQ + k] = v[r].y;
+      }
+    }
+  };
+  // this wave's row strip of a register tile, columns kq*KQ .. -> A image
+  auto park_strip = [&](double* dst, const double (&v)[NIW][NJ], int kq) __attribute__((always_inline)) {
+    const int l = lane(), i = l >> 4, cc = l & 15;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int col = 16 * J + cc - kq * KQ;
+        if (col >= 0 && col < KQ) dst[(4 * (wv * NT + ii) + i) * SQ + col] = v[ii][J];
+      }
+  };
+  auto gemm_q = [&](double (&acc)[NIW][NJ], const double* Xq, const double* Yq, bool negate) __attribute__((always_inline)) {
+    const int l = lane();
+    const double* xa = Xq + (4 * wv * NT + (l & 3)) * SQ + (l >> 4);
+    const double* yb = Yq + (l & 15) * SQ + (l >> 4);
+#pragma unroll
+    for (int k0 = 0; k0 < KQ; k0 += 4) {
       double av[NIW], bv[NJ];
 #pragma unroll
-      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * S + k0];
+      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * SQ + k0];
 #pragma unroll
-      for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * S + k0];
+      for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * SQ + k0];
 #pragma unroll
       for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
@@ -58,28 +119,42 @@ __global__ void __launch_bounds__(256) spectra_kernel(SpecArgs a) {
   for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
     for (int J = 0; J < NJ; ++J) tr[ii][J] = ti[ii][J] = 0.0;
-  gemm_nt(tr, L0, L2, false);   // Tr = Hr V
-  gemm_nt(ti, L1, L2, false);   // Ti = Hi V
-  __syncthreads();
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) {
-      const int o = (4 * (wv * NT + ii) + i) * S + 16 * J + cc;
-      L2[o] = tr[ii][J];
-      L3[o] = ti[ii][J];
+  f64x2 hv[NH], vv[NVV];
+  fetch_h(hv, 0);
+  fetch_v(vv, 0);
+  for (int kq = 0; kq < 4; ++kq) {                 // ---- stage 1
+    __syncthreads();                               // the previous quarter has been read
+    park_h(A0, A1, hv);
+    park_v(vv);
+    if (kq < 3) {
+      fetch_h(hv, kq + 1);
+      fetch_v(vv, kq + 1);
+    } else {
+      fetch_h(hv, 0);                              // first quarter of stage 2
     }
-  __syncthreads();
+    __syncthreads();
+    gemm_q(tr, A0, B0, false);                     // Tr += Hr V
+    gemm_q(ti, A1, B0, false);                     // Ti += Hi V
+  }
   double sr[NIW][NJ], si[NIW][NJ];
 #pragma unroll
   for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
     for (int J = 0; J < NJ; ++J) sr[ii][J] = si[ii][J] = 0.0;
-  gemm_nt(sr, L2, L0, false);   // Tr Hr^T
-  gemm_nt(sr, L3, L1, true);    // - Ti Hi^T
-  gemm_nt(si, L2, L1, false);   // Tr Hi^T
-  gemm_nt(si, L3, L0, false);   // + Ti Hr^T
+  for (int kq = 0; kq < 4; ++kq) {                 // ---- stage 2
+    __syncthreads();
+    park_strip(A0, tr, kq);
+    park_strip(A1, ti, kq);
+    park_h(B0, B1, hv);
+    if (kq < 3) fetch_h(hv, kq + 1);
+    __syncthreads();
+    gemm_q(sr, A0, B0, false);                     // Tr Hr^T
+    gemm_q(sr, A1, B1, true);                      // - Ti Hi^T
+    gemm_q(si, A0, B1, false);                     // Tr Hi^T
+    gemm_q(si, A1, B0, false);                     // + Ti Hr^T
+  }
   double2* So = reinterpret_cast<double2*>(a.S) + (size_t)gw * TILE;
+  const int l = lane(), i = l >> 4, cc = l & 15;
 #pragma unroll
   for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll

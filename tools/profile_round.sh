@@ -6,7 +6,7 @@
 # runtime trace -- then the plain bench line.  tools/summarise_profiles.py turns the raw output
 # under gpurun_out/ into the committed files under profiles/.
 set -eo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -26,3 +26,7 @@ echo "sq pass done"
 cd "$REPO"
 python3 bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"
+# side measurement: the ffDTF + spectra path (kernel stats only)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_spectra" -o run --output-format csv -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --with-spectra > "$OUT/stats_spectra.log" 2>&1 || echo "spectra stats pass failed (non-fatal)"
+cd "$REPO"
