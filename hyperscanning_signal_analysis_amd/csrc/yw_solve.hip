@@ -17,9 +17,9 @@
 // (semi)definite, so no pivoting is needed; a non-positive pivot is reported through `info` and becomes
 // numpy.linalg.LinAlgError("Singular matrix") in the Python layer, like the reference's dgesv failure.
 //
-// Mapping: one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by tile
-// column (diagonal tile kernel, then all tiles below it), the back substitution pivot block by pivot block,
-// so a batch of a few hundred windows still fills the chip.  Every tile product is an MP x MP x MP real
+// Mapping (tile form): one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by
+// tile column (diagonal tile kernel, then all tiles below it), so a batch of a few hundred windows still fills the
+// chip; the back substitution and the emit are one more launch with one workgroup per window (yw_window_kernel).  Every tile product is an MP x MP x MP real
 // GEMM on v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row stride 6 mod 32 doubles:
 // conflict-free A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the output tile.  The
 // p tile inverses D_b^-1 run on wave 0 as an in-register blocked Gauss-Jordan (same scheme as K3, real, no
@@ -364,49 +364,6 @@ __global__ void __launch_bounds__(256, 2) yw_col_kernel(YwArgs a, int tb) {
   if (ta == p) t.store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
 }
 
-// ---- back substitution with the unit lower factor, pivot block c:  Z[b] -= Z[c] Lt[c][b]  for b < c
-template <int NT>
-__global__ void __launch_bounds__(256, 2) yw_back_kernel(YwArgs a, int c) {
-  using T = YwTile<NT>;
-  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
-  __shared__ double Xs[MP * S];
-  __shared__ double Ys[MP * S];
-  T t(Xs, Ys);
-  const long long item = blockIdx.x;
-  const int b = blockIdx.y;
-  const YwPtrs q = yw_ptrs<MP>(a, item);
-  double z[NIW][NJ], acc[NIW][NJ];
-  t.load_tile(z, q.Zt + (size_t)b * TILE);
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-  t.stage2(q.Zt + (size_t)c * TILE, false, q.Lt + yw_tri(c, b) * TILE, true);
-  __syncthreads();
-  t.gemm_nt(acc);
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) z[ii][J] -= acc[ii][J];
-  t.store_tile(q.Zt + (size_t)b * TILE, z);
-}
-
-// ---- ar[item][row][col][k] = Z[k][row][col]  (lag fastest: the reference's (m, m, p) layout)
-template <int NT>
-__global__ void __launch_bounds__(256) yw_emit_kernel(YwArgs a) {
-  constexpr int MP = 16 * NT, TILE = MP * MP;
-  const long long item = blockIdx.x;
-  const int p = a.p;
-  const YwPtrs q = yw_ptrs<MP>(a, item);
-  double* ar = a.ar + (size_t)item * TILE * p;
-  // consecutive threads write consecutive addresses (lag fastest); the reads are p runs of 256/p elements
-  const int total = TILE * p;
-  for (int idx = blockIdx.y * 256 + threadIdx.x; idx < total; idx += gridDim.y * 256) {
-    const int e = idx / p, k = idx - e * p;
-    ar[idx] = q.Zt[(size_t)k * TILE + e];
-  }
-}
-
 
 // ---- one workgroup per window: the whole factorisation, back substitution and emit in ONE launch --------------
 // The tile-per-workgroup kernels above need ~50 dependent launches per batch (25 on the critical path), each
@@ -427,7 +384,9 @@ struct YwWin {
 
 // VQ: also the residual covariances of the lower orders (log det V_q, model-order criterion) -- its own
 // instantiation because the extra tile and inverse do not fit the 168 registers that three workgroups per CU allow.
-template <int NT, bool VQ>
+// BACK_ONLY: only the back substitution and the emit (the tail of the tile launch chain: one launch instead of the
+// p - 1 pivot-block launches + 2 emit launches of round 1).
+template <int NT, bool VQ, bool BACK_ONLY = false>
 __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
   using W = YwWin<NT>;
   constexpr int MP = W::MP, KH = W::KH, SH = W::SH, NIW = NT, NJ = NT, TILE = W::TILE, NV = W::NV, SI = W::SI;
@@ -586,7 +545,7 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
 
   double g[NIW][NJ], acc[NIW][NJ];
   const double (&none)[NIW][NJ] = g;
-  for (int tb = 0; tb <= p; ++tb) {
+  for (int tb = 0; tb <= (BACK_ONLY ? -1 : p); ++tb) {
     // ---- diagonal tile: D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ; D^-1 (tb < p) or V (tb == p)
     load_G(g, tb, tb);
     zero(acc);
@@ -631,21 +590,24 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
     }
     __syncthreads();                   // column tb of Y / Lt is complete before column tb + 1 reads it
   }
-  if (threadIdx.x == 0 && s_info != 0) a.info[item] = s_info;
-  // ---- back substitution with the unit lower factor: Z[b] -= Z[c] Lt[c][b] for b < c, c = p-1 .. 1
+  if (!BACK_ONLY && threadIdx.x == 0 && s_info != 0) a.info[item] = s_info;
+  // ---- back substitution with the unit lower factor: Z[b] = Lt[p][b] - sum_{c > b} Z[c] Lt[c][b].  Row by row
+  // (b = p-2 .. 0) with Z[b] kept in registers while its terms c = p-1 .. b+1 are subtracted one product at a time:
+  // every Z[b] sees the same subtractions in the same order as in the pivot-block-by-pivot-block form of the tile
+  // kernels (same bits), but is read and written once instead of once per term.
   __syncthreads();
-  for (int c = p - 1; c >= 1; --c) {
-    for (int b = 0; b < c; ++b) {
-      load_tile(g, q.Zt + (size_t)b * TILE);
+  for (int b = p - 2; b >= 0; --b) {
+    load_tile(g, q.Zt + (size_t)b * TILE);
+    for (int c = p - 1; c > b; --c) {
       zero(acc);
       product(acc, q.Zt + (size_t)c * TILE, none, q.Lt + yw_tri(c, b) * TILE, true);
 #pragma unroll
       for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
         for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-      store_tile(q.Zt + (size_t)b * TILE, g);
     }
-    __syncthreads();                   // Z[0 .. c-1] of this round before the next pivot block reads Z[c-1]
+    store_tile(q.Zt + (size_t)b * TILE, g);
+    __syncthreads();                   // Z[b] is in global memory before row b - 1 reads it
   }
   // ---- ar[item][row][col][k] = Z[k][row][col]  (lag fastest: the reference's (m, m, p) layout)
   double* ar = a.ar + (size_t)item * TILE * p;
@@ -665,8 +627,9 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(yw_diag_kernel<NT>, dim3(n), dim3(256), 0, st, a, tb);
     if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(n, p - tb), dim3(256), 0, st, a, tb);
   }
-  for (int c = p - 1; c >= 1; --c) hipLaunchKernelGGL(yw_back_kernel<NT>, dim3(n, c), dim3(256), 0, st, a, c);
-  hipLaunchKernelGGL(yw_emit_kernel<NT>, dim3(n, 16), dim3(256), 0, st, a);
+  // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 launches of yw_back_kernel, each
+  // re-reading and re-writing the Z tiles it updates, then yw_emit_kernel)
+  hipLaunchKernelGGL((yw_window_kernel<NT, false, true>), dim3(n), dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
