@@ -325,9 +325,16 @@ __global__ void __launch_bounds__(256, 2) yw_col_kernel(YwArgs a, int tb) {
   __shared__ double Xs[MP * S];
   __shared__ double Ys[MP * S];
   T t(Xs, Ys);
-  const long long item = blockIdx.x;
-  const int ta = tb + 1 + blockIdx.y;
+  // XCD-aware block -> (window, tile) map.  The p - tb tiles of one window all read the same tb tiles Y[tb][c] and the
+  // same D_tb^-1.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, and with it an L2), so the
+  // tiles of a window sit 8 blocks apart: groups of 8 windows x (p - tb) tiles, tile index slow, window-in-group fast.
+  // The shared operands then come from HBM once per window instead of once per tile.
   const int p = a.p;
+  const unsigned ntile = (unsigned)(p - tb);
+  const unsigned grp = blockIdx.x / (8u * ntile), r = blockIdx.x - grp * (8u * ntile);
+  const long long item = (long long)grp * 8 + (r & 7u);
+  if (item >= a.n_items) return;                       // padding of the last group (whole workgroup)
+  const int ta = tb + 1 + (int)(r >> 3);
   const YwPtrs q = yw_ptrs<MP>(a, item);
   double g[NIW][NJ], acc[NIW][NJ];
   t.load_G(g, q.R, ta, tb, p);
@@ -625,7 +632,7 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
   for (int tb = 0; tb <= p; ++tb) {
     hipLaunchKernelGGL(yw_diag_kernel<NT>, dim3(n), dim3(256), 0, st, a, tb);
-    if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(n, p - tb), dim3(256), 0, st, a, tb);
+    if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(((n + 7) / 8) * 8 * (p - tb)), dim3(256), 0, st, a, tb);
   }
   // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 launches of yw_back_kernel, each
   // re-reading and re-writing the Z tiles it updates, then yw_emit_kernel)

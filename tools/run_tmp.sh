@@ -3,7 +3,7 @@ set -eo pipefail
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/r02j
 mkdir -p "$OUT"
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > "$OUT/pytest.txt" 2>&1 || { tail -40 "$OUT/pytest.txt"; exit 1; }
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > "$OUT/pytest.txt" 2>&1 || { tail -40 "$OUT/pytest.txt"; exit 1; }
 tail -3 "$OUT/pytest.txt"
 for rep in 1 2 3; do
   python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/new_$rep.json" 2> "$OUT/new_$rep.err" || { tail "$OUT/new_$rep.err"; exit 1; }
