@@ -17,13 +17,17 @@
 // (semi)definite, so no pivoting is needed; a non-positive pivot is reported through `info` and becomes
 // numpy.linalg.LinAlgError("Singular matrix") in the Python layer, like the reference's dgesv failure.
 //
-// Mapping (tile form): one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by
-// tile column (diagonal tile kernel, then all tiles below it), so a batch of a few hundred windows still fills the
-// chip; the back substitution and the emit are one more launch with one workgroup per window (yw_window_kernel).  Every tile product is an MP x MP x MP real
-// GEMM on v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row stride 6 mod 32 doubles:
-// conflict-free A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the output tile.  The
-// p tile inverses D_b^-1 run on wave 0 as an in-register blocked Gauss-Jordan (same scheme as K3, real, no
-// pivot).
+// Two forms walk the same tile products in the same order (bit-identical results):
+//   * tile form: one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by tile
+//     column (diagonal tile kernel, then all tiles below it), so a batch of a few hundred windows still fills the
+//     chip; the back substitution and the emit are one more launch with one workgroup per window;
+//   * window form (yw_window_kernel): one workgroup per window does everything in one launch.
+// Every tile product is an MP x MP x MP real GEMM on v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row
+// stride 6 mod 32 doubles: conflict-free A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the
+// output tile.  The p tile inverses D_b^-1 are a cooperative 4-wave blocked Gauss-Jordan (spd_inverse_coop: the wave
+// that owns the panel columns factors them lane-per-row, every wave applies the rank-4 update on the matrix pipe;
+// same scheme as K3, real, no pivoting).  The stage as a whole is bound by HBM traffic, not by the matrix pipe
+// (~14 MB of tile operands and results per window).
 #include "hmv_common.h"
 #include "hmv_kernels.h"
 

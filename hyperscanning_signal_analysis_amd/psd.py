@@ -3,12 +3,15 @@
 PARITY UNPINNED: the reference delegates to mne==1.11.0 (`psd_array_multitaper`), which is not available
 offline; the kernel path restates that algorithm with mne's defaults (see include/hypermvar.h,
 `hmv_psd_multitaper_f64`, and oracle/psd_oracle.py).  DPSS tapers are computed on the host by SciPy (what mne
-itself calls) and cached per (n_times, time-half-bandwidth); everything per sample runs on the device:
+itself calls) and cached per (n_times, time-half-bandwidth) in memory and on disk; everything per sample runs on
+the device:
 taper products, batched real-to-complex FFTs (hipFFT) and the eigenvalue-weighted power sum.
 """
 from __future__ import annotations
 
 import functools
+import os
+import tempfile
 
 import numpy as np
 import torch
@@ -19,8 +22,30 @@ from .engine import default_engine
 __all__ = ["compute_psd_multitaper", "average_psd_across_conditions"]
 
 
+def _taper_cache_dir():
+    """Where DPSS tapers are kept between processes: $HYPERMVAR_DPSS_CACHE, default <tmp>/hypermvar_dpss ('' = off)."""
+    d = os.environ.get("HYPERMVAR_DPSS_CACHE")
+    if d == "":
+        return None
+    return d or os.path.join(tempfile.gettempdir(), "hypermvar_dpss")
+
+
 @functools.lru_cache(maxsize=8)
 def _tapers(n_times: int, half_nbw: float):
+    """(tapers (K, n_times), sqrt(eigenvalues)) as mne selects them (low_bias: eigenvalue > 0.9).  SciPy's DPSS is the
+    host-bound part of the PSD leg (55 s for a 220 s segment at 500 Hz, 438 tapers, against 76 ms on the GPU for the
+    whole PSD), and a batch meets the same (length, bandwidth) again and again: the tapers are cached in memory per
+    process and on disk across processes and ranks (plain .npz, written atomically)."""
+    path = None
+    cdir = _taper_cache_dir()
+    if cdir is not None:
+        path = os.path.join(cdir, f"dpss_n{n_times}_nw{half_nbw!r}.npz")
+        if os.path.exists(path):
+            try:
+                with np.load(path, allow_pickle=False) as z:
+                    return np.ascontiguousarray(z["tapers"]), np.ascontiguousarray(z["weights"])
+            except Exception:          # unreadable or half-written file: recompute
+                pass
     from scipy.signal.windows import dpss
     k_max = max(int(2 * half_nbw), 1)
     tapers, eig = dpss(n_times, half_nbw, k_max, sym=False, norm=2, return_ratios=True)
@@ -29,7 +54,17 @@ def _tapers(n_times: int, half_nbw: float):
     if not idx.any():
         idx = np.zeros_like(idx)
         idx[np.argmax(eig)] = True
-    return np.ascontiguousarray(tapers[idx]), np.sqrt(eig[idx])
+    tapers, weights = np.ascontiguousarray(tapers[idx]), np.sqrt(eig[idx])
+    if path is not None:
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                np.savez(f, tapers=tapers, weights=weights)
+            os.replace(tmp, path)
+        except OSError:                # read-only or full disk: the cache is an optimisation only
+            pass
+    return tapers, weights
 
 
 def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30, engine=None):

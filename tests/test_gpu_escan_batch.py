@@ -62,18 +62,6 @@ def tree(tmp_path):
     return root
 
 
-def test_discovery_and_event_decoding(tree):
-    found = EB.discover_dyads(tree)
-    assert sorted(found) == ["W_003", "W_010", "W_020", "W_030"]
-    assert sorted(found["W_003"]) == ["passive_movies", "talk"] and sorted(found["W_003"]["talk"]) == ["cg", "ch"]
-    assert list(EB.discover_dyads(tree, tasks=("talk",))["W_010"]) == ["talk"]
-    rec = _reader(found["W_003"]["passive_movies"]["ch"])
-    assert EB.decode_events(rec["attrs"]) == [("Peppa", 1.0, 11.0), ("Brave", 14.0, 9.5)]
-    assert EB.decode_events({"task_events_structure": ""}) == [] and EB.decode_events({}) == []
-    with pytest.raises(FileNotFoundError):
-        EB.discover_dyads(tree / "nowhere")
-
-
 def test_batch_matches_oracle_per_window_and_keeps_books(tree, tmp_path, capsys):
     out = tmp_path / "ffdtf_out"
     freqs = np.arange(1.0, 33.0, 1.0)                            # 32 points: the in-kernel normalisation path
