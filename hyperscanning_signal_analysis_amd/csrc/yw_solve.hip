@@ -30,6 +30,7 @@
 // (~14 MB of tile operands and results per window).
 #include "hmv_common.h"
 #include "hmv_kernels.h"
+#include <cstdlib>
 
 namespace hmv {
 
@@ -142,107 +143,6 @@ __device__ __forceinline__ void spd_inverse_coop(const double* Xs, double* Pb, d
   }
 }
 
-// Shared pieces of the three kernels: tile staging, the MP^3 tile product, tile I/O in the D layout.
-template <int NT>
-struct YwTile {
-  using C = YwCfg<NT>;
-  static constexpr int MP = C::MP, S = C::S, NIW = NT, NJ = NT, TILE = MP * MP, NPT = TILE / 256;
-  double* Xs;
-  double* Ys;
-  int l, wv, i, cc;
-
-  __device__ __forceinline__ YwTile(double* xs, double* ys) : Xs(xs), Ys(ys) {
-    l = lane_id();
-    wv = uni(threadIdx.x >> 6);
-    i = l >> 4;
-    cc = l & 15;
-  }
-  // Both operand tiles of a product are fetched with ALL loads in flight before the first LDS store
-  // (a load->store loop serialises on the ~1 us global latency 16 times per tile).
-  __device__ __forceinline__ void stage2(const double* srcX, bool trX, const double* srcY, bool trY) const {
-    double vx[NPT], vy[NPT];
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) vx[r] = srcX ? srcX[threadIdx.x + 256 * r] : 0.0;
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) vy[r] = srcY[threadIdx.x + 256 * r];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) {
-      const int idx = threadIdx.x + 256 * r;
-      const int row = idx / MP, col = idx - row * MP;
-      if (srcX) Xs[trX ? col * S + row : row * S + col] = vx[r];
-      Ys[trY ? col * S + row : row * S + col] = vy[r];
-    }
-  }
-  // split form for software pipelining: issue the global loads of the NEXT product's tiles, run the current
-  // product on the matrix pipe, then park the prefetched tiles in LDS
-  __device__ __forceinline__ void fetch2(double (&vx)[NPT], double (&vy)[NPT], const double* srcX, const double* srcY) const {
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) vx[r] = srcX[threadIdx.x + 256 * r];
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) vy[r] = srcY[threadIdx.x + 256 * r];
-  }
-  __device__ __forceinline__ void park2(const double (&vx)[NPT], const double (&vy)[NPT]) const {
-#pragma unroll
-    for (int r = 0; r < NPT; ++r) {
-      const int idx = threadIdx.x + 256 * r;
-      const int row = idx / MP, col = idx - row * MP;
-      Xs[row * S + col] = vx[r];
-      Ys[row * S + col] = vy[r];
-    }
-  }
-  // acc[ii][J] += Xs(rows of this wave) * Ys^T
-  __device__ __forceinline__ void gemm_nt(double (&acc)[NIW][NJ]) const {
-    const double* xa = Xs + (4 * wv * NT + (l & 3)) * S + (l >> 4);
-    const double* yb = Ys + cc * S + (l >> 4);
-#pragma unroll 2
-    for (int k0 = 0; k0 < MP; k0 += 4) {
-      double av[NIW], bv[NJ];
-#pragma unroll
-      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * S + k0];
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * S + k0];
-#pragma unroll
-      for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-        for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[ii], bv[J], acc[ii][J]);
-    }
-  }
-  __device__ __forceinline__ int row_of(int ii) const { return 4 * (wv * NT + ii) + i; }
-  __device__ __forceinline__ void load_tile(double (&v)[NIW][NJ], const double* src) const {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) v[ii][J] = src[(size_t)row_of(ii) * MP + 16 * J + cc];
-  }
-  __device__ __forceinline__ void store_tile(double* dst, const double (&v)[NIW][NJ]) const {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) dst[(size_t)row_of(ii) * MP + 16 * J + cc] = v[ii][J];
-  }
-  __device__ __forceinline__ void strip_to_lds(double* dst, const double (&v)[NIW][NJ]) const {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) dst[row_of(ii) * S + 16 * J + cc] = v[ii][J];
-  }
-  // tile (ta, tb) of the augmented matrix, straight from the lag covariances
-  __device__ __forceinline__ void load_G(double (&g)[NIW][NJ], const double* R, int ta, int tb, int p) const {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) {
-        const int row = row_of(ii), col = 16 * J + cc;
-        double v;
-        if (ta < p) v = R[(size_t)(ta - tb) * TILE + row * MP + col];
-        else if (tb < p) v = R[(size_t)(tb + 1) * TILE + col * MP + row];
-        else v = R[row * MP + col];
-        g[ii][J] = v;
-      }
-  }
-};
-
 struct YwPtrs {
   const double* R;
   double *Yt, *Lt, *Dinv, *Zt;
@@ -262,128 +162,15 @@ __device__ __forceinline__ YwPtrs yw_ptrs(const YwArgs& a, long long item) {
   return q;
 }
 
-// The factorisation is launched tile column by tile column (and the back substitution pivot block by pivot
-// block): one workgroup per window cannot fill 256 CUs (599 windows per 10-minute dyad), one workgroup
-// per (window, tile) can.
-//
-// ---- diagonal tile (tb, tb):  D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ;  D^-1 (tb < p) or V (tb == p)
-template <int NT>
-__global__ void __launch_bounds__(256, 2) yw_diag_kernel(YwArgs a, int tb) {
-  using T = YwTile<NT>;
-  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
-  __shared__ double Xs[MP * S];
-  __shared__ double Ys[MP * S];
-  __shared__ double Pb[MP * 4];
-  __shared__ double Nb[2 * MP * 4];
-  T t(Xs, Ys);
-  const long long item = blockIdx.x;
-  const int p = a.p;
-  const YwPtrs q = yw_ptrs<MP>(a, item);
-  __shared__ int s_info;
-  __shared__ double s_ld[4];
-  if (threadIdx.x == 0) s_info = 0;
-  double g[NIW][NJ], acc[NIW][NJ];
-  t.load_G(g, q.R, tb, tb, p);
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-  for (int c = 0; c < tb; ++c) {
-    __syncthreads();
-    t.stage2(q.Lt + yw_tri(tb, c) * TILE, false, q.Yt + yw_tri(tb, c) * TILE, false);
-    __syncthreads();
-    t.gemm_nt(acc);
-    if (a.Vq_logdet && tb == p) {   // V_{c+1} = R_0 - sum_{c' <= c} ... : residual covariance of order c+1
-      double vq[NIW][NJ];
-#pragma unroll
-      for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-        for (int J = 0; J < NJ; ++J) vq[ii][J] = g[ii][J] - acc[ii][J];
-      __syncthreads();
-      t.strip_to_lds(Xs, vq);
-      __syncthreads();
-      spd_inverse_coop<NT, S>(Xs, Pb, Nb, &s_info, s_ld, nullptr, a.Vq_logdet + (size_t)item * p + c, tb * MP);
-    }
-  }
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-  if (tb < p) {
-    __syncthreads();
-    t.strip_to_lds(Xs, g);
-    __syncthreads();
-    spd_inverse_coop<NT, S>(Xs, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_info != 0) atomicCAS(&a.info[item], 0, s_info);
-  } else {
-    t.store_tile(a.V + (size_t)item * TILE, g);
-  }
-}
-
-// ---- off-diagonal tiles (ta, tb), ta = tb+1 .. p:  Y = G - sum_c Lt[ta][c] Y[tb][c]^T ;  Lt = Y D_tb^-1
-template <int NT>
-__global__ void __launch_bounds__(256, 2) yw_col_kernel(YwArgs a, int tb) {
-  using T = YwTile<NT>;
-  constexpr int MP = T::MP, S = T::S, NIW = NT, NJ = NT, TILE = T::TILE;
-  __shared__ double Xs[MP * S];
-  __shared__ double Ys[MP * S];
-  T t(Xs, Ys);
-  // XCD-aware block -> (window, tile) map.  The p - tb tiles of one window all read the same tb tiles Y[tb][c] and the
-  // same D_tb^-1.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, and with it an L2), so the
-  // tiles of a window sit 8 blocks apart: groups of 8 windows x (p - tb) tiles, tile index slow, window-in-group fast.
-  // The shared operands then come from HBM once per window instead of once per tile.
-  const int p = a.p;
-  const unsigned ntile = (unsigned)(p - tb);
-  const unsigned grp = blockIdx.x / (8u * ntile), r = blockIdx.x - grp * (8u * ntile);
-  const long long item = (long long)grp * 8 + (r & 7u);
-  if (item >= a.n_items) return;                       // padding of the last group (whole workgroup)
-  const int ta = tb + 1 + (int)(r >> 3);
-  const YwPtrs q = yw_ptrs<MP>(a, item);
-  double g[NIW][NJ], acc[NIW][NJ];
-  t.load_G(g, q.R, ta, tb, p);
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-  {
-    double vx[T::NPT], vy[T::NPT];
-    if (tb > 0) t.fetch2(vx, vy, q.Lt + yw_tri(ta, 0) * TILE, q.Yt + yw_tri(tb, 0) * TILE);
-    for (int c = 0; c < tb; ++c) {
-      __syncthreads();                 // previous product has finished reading Xs / Ys
-      t.park2(vx, vy);
-      __syncthreads();
-      if (c + 1 < tb) t.fetch2(vx, vy, q.Lt + yw_tri(ta, c + 1) * TILE, q.Yt + yw_tri(tb, c + 1) * TILE);
-      t.gemm_nt(acc);                  // the next tiles' loads are in flight behind these MFMAs
-    }
-  }
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-  t.store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
-  __syncthreads();
-  t.strip_to_lds(Xs, g);
-  t.stage2(nullptr, false, q.Dinv + (size_t)tb * TILE, true);
-  __syncthreads();
-#pragma unroll
-  for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-    for (int J = 0; J < NJ; ++J) acc[ii][J] = 0.0;
-  t.gemm_nt(acc);
-  t.store_tile(q.Lt + yw_tri(ta, tb) * TILE, acc);
-  if (ta == p) t.store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
-}
-
-
-// ---- one workgroup per window: the whole factorisation, back substitution and emit in ONE launch --------------
-// The tile-per-workgroup kernels above need ~50 dependent launches per batch (25 on the critical path), each
-// one round of at most 1.2 workgroups per CU: 2.0 ms for 599 windows, 0.30 of the f64 peak.  Here a workgroup
-// walks the same left-looking schedule for its window on its own -- same tile products in the same order, so
-// the results are bit-identical -- with the scratch tiles in global memory (private to the workgroup: only
-// workgroup barriers order them) and the operands staged through LDS in two k-halves (39 KB, so three
-// workgroups fit a CU and a 599-window batch is resident at once; co-resident workgroups hide each other's
-// staging latency and the serial 64 x 64 inverses).
+// ---- the kernel of both forms ---------------------------------------------------------------------------------
+// Window form (MODE 0): one workgroup walks the whole left-looking schedule of its window in ONE launch, with the
+// scratch tiles in global memory (private to the workgroup: only workgroup barriers order them).  Tile form: the same
+// kernel body per tile -- MODE 3 one diagonal tile, MODE 2 one off-diagonal tile per workgroup, launched tile column
+// by tile column, then MODE 1 (back substitution + emit, one workgroup per window): 18 launches per batch (round 1:
+// ~50), each filling the chip.  Same tile products in the same order either way: bit-identical results.
+// Operands are staged through LDS in two k-halves (39 KB + the inverse's panels: four column-tile workgroups or three
+// window workgroups per CU; round 1 staged whole tiles, 72-78 KB, two per CU), the second half's loads in flight
+// behind the first half's MFMAs.
 template <int NT>
 struct YwWin {
   static constexpr int MP = 16 * NT, KH = MP / 2, SH = KH + 6, NIW = NT, NJ = NT, TILE = MP * MP;
@@ -395,10 +182,15 @@ struct YwWin {
 
 // VQ: also the residual covariances of the lower orders (log det V_q, model-order criterion) -- its own
 // instantiation because the extra tile and inverse do not fit the 168 registers that three workgroups per CU allow.
-// BACK_ONLY: only the back substitution and the emit (the tail of the tile launch chain: one launch instead of the
-// p - 1 pivot-block launches + 2 emit launches of round 1).
-template <int NT, bool VQ, bool BACK_ONLY = false>
-__global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
+// MODE 0: the whole window.  MODE 1 (tile launch chain): only the back substitution and the emit, one launch instead
+// of the p - 1 pivot-block launches + 2 emit launches of round 1.  MODE 2 (tile launch chain): ONE off-diagonal tile
+// (ta, tb_arg) of one window per workgroup -- the column kernel of the chain with this kernel's k-half staging
+// (39 KB of LDS, 98 VGPRs: four workgroups per CU instead of the two of round 1's whole-tile column kernel, and the
+// second k-half's loads in flight behind the first half's MFMAs: 127 -> 114 us per launch).  MODE 3: ONE diagonal tile
+// (tb_arg) per workgroup, the diagonal kernel of the chain, likewise.
+template <int NT, bool VQ, int MODE = 0>
+__global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, int tb_arg) {
+  constexpr bool BACK_ONLY = (MODE == 1);
   using W = YwWin<NT>;
   constexpr int MP = W::MP, KH = W::KH, SH = W::SH, NIW = NT, NJ = NT, TILE = W::TILE, NV = W::NV, SI = W::SI;
   __shared__ __attribute__((aligned(16))) double buf[W::BUF_D];
@@ -409,8 +201,18 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
   double* Xh = buf;                 // [MP][SH]  k-half of the A-operand tile
   double* Yh = buf + MP * SH;       // [MP][SH]  k-half of the B-operand tile (rows = output columns)
   const int wv = uni(threadIdx.x >> 6);
-  const long long item = blockIdx.x;
   const int p = a.p;
+  long long item = blockIdx.x;
+  int ta_col = 0;
+  if (MODE == 2) {
+    // XCD-aware block -> (window, tile) map: the p - tb tiles of one window read the same tb tiles Y[tb][c] and the
+    // same D_tb^-1; blocks b and b + 8 share an XCD (and its L2), so the tiles of a window sit 8 blocks apart.
+    const unsigned ntile = (unsigned)(p - tb_arg);
+    const unsigned grp = blockIdx.x / (8u * ntile), r = blockIdx.x - grp * (8u * ntile);
+    item = (long long)grp * 8 + (r & 7u);
+    if (item >= a.n_items) return;                       // padding of the last group (whole workgroup)
+    ta_col = tb_arg + 1 + (int)(r >> 3);
+  }
   const YwPtrs q = yw_ptrs<MP>(a, item);
   if (threadIdx.x == 0) s_info = 0;
 
@@ -556,7 +358,24 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
 
   double g[NIW][NJ], acc[NIW][NJ];
   const double (&none)[NIW][NJ] = g;
-  for (int tb = 0; tb <= (BACK_ONLY ? -1 : p); ++tb) {
+  if (MODE == 2) {                     // Y = G - sum_c Lt[ta][c] Y[tb][c]^T ; Lt = Y D^-1   
+    const int tb = tb_arg, ta = ta_col;
+    zero(acc);
+    for (int c = 0; c < tb; ++c)
+      product(acc, q.Lt + yw_tri(ta, c) * TILE, none, q.Yt + yw_tri(tb, c) * TILE, false);
+    load_G(g, ta, tb);
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
+    store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
+    zero(acc);
+    product(acc, nullptr, g, q.Dinv + (size_t)tb * TILE, true);
+    store_tile(q.Lt + yw_tri(ta, tb) * TILE, acc);
+    if (ta == p) store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
+    return;
+  }
+  for (int tb = (MODE == 3 ? tb_arg : 0); tb <= (BACK_ONLY ? -1 : (MODE == 3 ? tb_arg : p)); ++tb) {
     // ---- diagonal tile: D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ; D^-1 (tb < p) or V (tb == p)
     load_G(g, tb, tb);
     zero(acc);
@@ -578,11 +397,16 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a) {
       for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
     if (tb == p) {
       store_tile(a.V + (size_t)item * TILE, g);
+      if (MODE == 3) return;
       break;
     }
     tile_to_lds(g);
     spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
     __syncthreads();                   // D^-1 is in global memory for the whole workgroup
+    if (MODE == 3) {                   // tile launch chain: the column tiles are the next launch
+      if (threadIdx.x == 0 && s_info != 0) atomicCAS(&a.info[item], 0, s_info);
+      return;
+    }
     // ---- tiles below it: Y = G - sum_c Lt[ta][c] Y[tb][c]^T ; Lt = Y D^-1
     for (int ta = tb + 1; ta <= p; ++ta) {
       load_G(g, ta, tb);
@@ -635,12 +459,14 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   const unsigned n = (unsigned)a.n_items;
   (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
   for (int tb = 0; tb <= p; ++tb) {
-    hipLaunchKernelGGL(yw_diag_kernel<NT>, dim3(n), dim3(256), 0, st, a, tb);
-    if (tb < p) hipLaunchKernelGGL(yw_col_kernel<NT>, dim3(((n + 7) / 8) * 8 * (p - tb)), dim3(256), 0, st, a, tb);
+    if (a.Vq_logdet && tb == p) hipLaunchKernelGGL((yw_window_kernel<NT, true, 3>), dim3(n), dim3(256), 0, st, a, tb);
+    else hipLaunchKernelGGL((yw_window_kernel<NT, false, 3>), dim3(n), dim3(256), 0, st, a, tb);
+    if (tb < p)
+      hipLaunchKernelGGL((yw_window_kernel<NT, false, 2>), dim3(((n + 7) / 8) * 8 * (p - tb)), dim3(256), 0, st, a, tb);
   }
   // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 launches of yw_back_kernel, each
   // re-reading and re-writing the Z tiles it updates, then yw_emit_kernel)
-  hipLaunchKernelGGL((yw_window_kernel<NT, false, true>), dim3(n), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((yw_window_kernel<NT, false, 1>), dim3(n), dim3(256), 0, st, a, 0);
   return (int)hipGetLastError();
 }
 
@@ -656,14 +482,14 @@ int launch_yw(const YwArgs& a, int m_pad, hipStream_t st) {
     const dim3 grid((unsigned)a.n_items), block(256);
     const bool vq = (a.Vq_logdet != nullptr);
     switch (m_pad) {
-      case 16: if (vq) hipLaunchKernelGGL((yw_window_kernel<1, true>), grid, block, 0, st, a);
-               else hipLaunchKernelGGL((yw_window_kernel<1, false>), grid, block, 0, st, a); break;
-      case 32: if (vq) hipLaunchKernelGGL((yw_window_kernel<2, true>), grid, block, 0, st, a);
-               else hipLaunchKernelGGL((yw_window_kernel<2, false>), grid, block, 0, st, a); break;
-      case 48: if (vq) hipLaunchKernelGGL((yw_window_kernel<3, true>), grid, block, 0, st, a);
-               else hipLaunchKernelGGL((yw_window_kernel<3, false>), grid, block, 0, st, a); break;
-      case 64: if (vq) hipLaunchKernelGGL((yw_window_kernel<4, true>), grid, block, 0, st, a);
-               else hipLaunchKernelGGL((yw_window_kernel<4, false>), grid, block, 0, st, a); break;
+      case 16: if (vq) hipLaunchKernelGGL((yw_window_kernel<1, true>), grid, block, 0, st, a, 0);
+               else hipLaunchKernelGGL((yw_window_kernel<1, false>), grid, block, 0, st, a, 0); break;
+      case 32: if (vq) hipLaunchKernelGGL((yw_window_kernel<2, true>), grid, block, 0, st, a, 0);
+               else hipLaunchKernelGGL((yw_window_kernel<2, false>), grid, block, 0, st, a, 0); break;
+      case 48: if (vq) hipLaunchKernelGGL((yw_window_kernel<3, true>), grid, block, 0, st, a, 0);
+               else hipLaunchKernelGGL((yw_window_kernel<3, false>), grid, block, 0, st, a, 0); break;
+      case 64: if (vq) hipLaunchKernelGGL((yw_window_kernel<4, true>), grid, block, 0, st, a, 0);
+               else hipLaunchKernelGGL((yw_window_kernel<4, false>), grid, block, 0, st, a, 0); break;
       default: return -1;
     }
     return (int)hipGetLastError();
