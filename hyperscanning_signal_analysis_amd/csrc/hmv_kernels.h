@@ -43,7 +43,7 @@ struct YwArgs {
   double* V;                // [n_items][MP][MP]
   double* Vq_logdet;        // optional [n_items][p]: log det V_q for q = 1..p (model-order criterion)
   int* info;                // [n_items]
-  int tiled;                // 0: one workgroup per window, one launch;  1: one workgroup per tile, ~50 launches;
+  int tiled;                // 0: one workgroup per window, one launch;  1: one workgroup per tile, 18 launches;
                             // -1: pick by batch shape (launch_yw)
 };
 long long yw_ws_tiles(int p);

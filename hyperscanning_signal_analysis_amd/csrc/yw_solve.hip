@@ -464,8 +464,8 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
     if (tb < p)
       hipLaunchKernelGGL((yw_window_kernel<NT, false, 2>), dim3(((n + 7) / 8) * 8 * (p - tb)), dim3(256), 0, st, a, tb);
   }
-  // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 launches of yw_back_kernel, each
-  // re-reading and re-writing the Z tiles it updates, then yw_emit_kernel)
+  // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 pivot-block launches, each
+  // re-reading and re-writing the Z tiles it updates, then two emit launches)
   hipLaunchKernelGGL((yw_window_kernel<NT, false, 1>), dim3(n), dim3(256), 0, st, a, 0);
   return (int)hipGetLastError();
 }

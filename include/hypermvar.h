@@ -145,7 +145,7 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
 #define HMV_FLAG_UNFUSED_NORM 1   /* ffDTF normalisation as a separate pass over |H|^2 (K4) instead of inside K3 */
 #define HMV_FLAG_DIRECT_LAGCOV 8   /* K1 sums every window from its own samples even on a regular grid (results then do
                                      not depend on how the windows are laid out: bit-identical across grids) */
-#define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in ~50 launches, and                          */
+#define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in 18 launches (tile column by tile column), and */
 #define HMV_FLAG_YW_ONE_LAUNCH 4  /* K2 as one workgroup per window in one launch: same tile products in the same
                                      order, same bits.  Neither flag: one launch, except for large 64-channel
                                      batches, where both forms are HBM-bound and the launch chain is faster. */
@@ -178,7 +178,7 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
  * ev_k3_start / ev_k3_stop (optional hipEvent_t, NULL to skip) are recorded on `stream` right before
  * and after the LAST chunk's K3 launch, so a caller can time the dominant kernel inside its own timed
  * region without an extra synchronisation.
- * aux_stream (optional second hipStream_t, NULL to disable; used by the tiled form of K2 only): ~25 dependent
+ * aux_stream (optional second hipStream_t, NULL to disable; used by the tiled form of K2 only): a chain of dependent
  * launches that cannot fill the chip -- it runs as two half-batches, one per stream (fork
  * after K1, join before K3), so their launches interleave on the device; the call still behaves as one
  * operation on `stream`. */
