@@ -45,7 +45,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "hmv_sliding_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "hmv_tf_ffdtf_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
-    "hmv_tf_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+    "hmv_tf_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_double, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hmv_sliding_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,

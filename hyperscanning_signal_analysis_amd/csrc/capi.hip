@@ -263,7 +263,7 @@ int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F) {
 }
 
 int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* ffdtf,
-                     double* den, int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes,
+                     double* den, double* H, int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes,
                      int64_t flags, void* ev_k3_start, void* ev_k3_stop, void* stream) {
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_tf_ffdtf_f64: channel count must be in 1..64");
@@ -279,6 +279,7 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
   hmv::TfArgs a{};
   a.ar = ar; a.arx = reinterpret_cast<double*>(base + w.off_arx); a.tw = tw;
   a.P = reinterpret_cast<double*>(base + w.off_P); a.rowsum = reinterpret_cast<double*>(base + w.off_rowsum);
+  a.H = H;
   a.info = info; a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   // the in-kernel normaliser moves 16 bytes per lane: whole 16-frequency lines of a 16-byte aligned output
   const bool fused = !(flags & HMV_FLAG_UNFUSED_NORM) && (F % 16 == 0) && (reinterpret_cast<uintptr_t>(ffdtf) % 16 == 0);
@@ -435,7 +436,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     if (c1 > 0) (void)hipStreamWaitEvent(st0, fj->join, 0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
-    rc = hmv_tf_ffdtf_f64(ar_c, c, m, p, tw, F, ffdtf + (size_t)i0 * m * m * F, den, info_tf + (size_t)i0 * F, pivot_tau,
+    rc = hmv_tf_ffdtf_f64(ar_c, c, m, p, tw, F, ffdtf + (size_t)i0 * m * m * F, den, nullptr, info_tf + (size_t)i0 * F, pivot_tau,
                           tfws, tfws_bytes, flags, last ? ev_k3_start : nullptr, last ? ev_k3_stop : nullptr, st0);
   }
   return rc;

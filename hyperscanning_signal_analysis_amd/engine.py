@@ -382,7 +382,7 @@ class Engine:
                               freqs, fs: float, chunk: int = 64, check: bool = True, out_ff=None, out_S=None):
         """Both products the reference's orchestrators always compute together (full_freq_dtf + multivariate_spectra,
         /root/reference/src/eeg_alpha_ibi_ffdtf.py:592-604, src/mtmvar.py:1100-1113) from ONE fit and ONE set of
-        inverses per window: K1 -> K2 -> K3 (|H|^2 and H) -> K4 -> K5 -> layout transpose, `chunk` windows at a time
+        inverses per window: K1 -> K2 -> K3 (ffDTF normalised in-kernel, H out) -> K5 -> layout transpose, `chunk` windows at a time
         (H and S are 16.8 MB per window each).  Returns (ffdtf (items, m, m, F) real, S (items, m, m, F) complex)."""
         assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
         x = x if x.stride(2) == 1 else x.contiguous()
@@ -402,15 +402,21 @@ class Engine:
             sl = slice(i0, min(n_items, i0 + chunk))
             R = self.lagcov(x, item_rec[sl], item_start[sl], n, p)
             ar, V, _, info_yw = self.yw_solve(R, m)
-            t = self.transfer(ar, m, tw, want_P=True, want_H=True)
-            c = ar.shape[0]
-            den = self.empty(c, t["P"].shape[2])
+            c, mp = ar.shape[0], ar.shape[1]
+            H = self.empty(c, F, mp, mp, 2)
+            den = self.empty(c, mp)
+            info_tf = self.empty(c * F, dtype=torch.int32)
+            nws = int(self.lib.hmv_tf_ffdtf_workspace_bytes(c, m, p, F))
+            ws = self._workspace(nws)
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.hmv_ffdtf_norm_f64(t["P"].data_ptr(), t["rowsum"].data_ptr(), den.data_ptr(),
-                                                       ff[sl].data_ptr(), c, F, m, 1, self.stream()), "hmv_ffdtf_norm_f64")
-                Sk = self.spectra(t["H"], V, m)
+                # K3 with the ffDTF normalisation inside AND H out: one set of inverses for both products
+                _lib.check(self.lib.hmv_tf_ffdtf_f64(ar.data_ptr(), c, m, p, tw.data_ptr(), F, ff[sl].data_ptr(),
+                                                     den.data_ptr(), H.data_ptr(), info_tf.data_ptr(), self.pivot_tau,
+                                                     ws.data_ptr(), nws, 0, 0, 0, self.stream()), "hmv_tf_ffdtf_f64")
+                Sk = self.spectra(H, V, m)
                 _lib.check(self.lib.hmv_transpose_c128(Sk.data_ptr(), S[sl].data_ptr(), c, F, m, self.stream()),
                            "hmv_transpose_c128")
+            t = {"info": info_tf}
             infos.append((info_yw, t["info"]))
         if check:
             for info_yw, info_tf in infos:

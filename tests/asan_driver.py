@@ -38,9 +38,9 @@ bad = [
     lib.hmv_tf_f64(D, 1, 99, 2, D, 4, D, D, 0, 0, D, 1.0, D, 0),
     lib.hmv_tf_f64(D, 1, 4, 2, D, 4, D, 0, 0, 0, D, 1.0, D, 0),
     lib.hmv_tf_f64(D, 1, 4, 2, D, 4, D, D, 0, 0, D, 0.0, D, 0),
-    lib.hmv_tf_ffdtf_f64(D, 1, 99, 2, D, 4, D, D, D, 1.0, D, 1 << 20, 0, 0, 0, 0),
-    lib.hmv_tf_ffdtf_f64(D, 5, 4, 2, D, 4, D, D, D, 1.0, D, 16, 0, 0, 0, 0),
-    lib.hmv_tf_ffdtf_f64(D, 5, 4, 2, D, 4, D, D, D, 2.0, D, 1 << 30, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_f64(D, 1, 99, 2, D, 4, D, D, 0, D, 1.0, D, 1 << 20, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_f64(D, 5, 4, 2, D, 4, D, D, D, D, 1.0, D, 16, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_f64(D, 5, 4, 2, D, 4, D, D, 0, D, 2.0, D, 1 << 30, 0, 0, 0, 0),
     lib.hmv_ffdtf_norm_f64(D, D, D, D, 1, 4, 99, 1, 0),
     lib.hmv_ffdtf_norm_f64(0, D, D, D, 1, 4, 4, 1, 0),
     lib.hmv_transpose_c128(0, D, 1, 4, 4, 0),
@@ -61,6 +61,6 @@ bad = [
 ]
 assert all(rc < 0 for rc in bad), bad
 assert lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == 0
-assert lib.hmv_tf_ffdtf_f64(D, 0, 4, 2, D, 4, D, D, D, 1.0, D, 0, 0, 0, 0, 0) == 0        # empty batches: nothing to do
+assert lib.hmv_tf_ffdtf_f64(D, 0, 4, 2, D, 4, D, D, 0, D, 1.0, D, 0, 0, 0, 0, 0) == 0        # empty batches: nothing to do
 assert len(lib.hmv_last_error()) > 0
 print(f"asan driver ok: {n + len(bad)} calls")

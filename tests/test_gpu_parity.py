@@ -476,6 +476,30 @@ def test_lag_covariances_from_shared_hop_blocks(m, n, hop, p, T, first):
         eng.lagcov_regular(xd[0], first, hop, n_win + 1 + (T - first - n) // hop, n, p)       # past the recording
 
 
+@pytest.mark.parametrize("m,n,p,F,nw,chunk", [(64, 1000, 8, 32, 40, 33), (19, 400, 3, 20, 9, 4), (4, 160, 5, 30, 5, 64)])
+def test_ffdtf_and_spectra_of_every_window_from_one_fit(m, n, p, F, nw, chunk):
+    """`Engine.sliding_ffdtf_spectra`: what the reference's orchestrators compute per window with two separate fits
+    (full_freq_dtf + multivariate_spectra, eeg_alpha_ibi_ffdtf.py:592-604) from ONE fit and ONE set of inverses, batched.
+    ffDTF equals the ffDTF-only path bit for bit (same K1 form), spectra equal the oracle's H V H^T (plain transpose)."""
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(17, m=m, p=min(p, 4), T=T, burn=300)
+    freqs = np.linspace(1.0, 100.0, F)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    ff, S = eng.sliding_ffdtf_spectra(xd, rec, st, w, p, freqs, 500.0, chunk=chunk)
+    only = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)               # no grid declared: same (direct) K1
+    torch.cuda.synchronize()
+    assert ff.shape == (nw, m, m, F) and S.shape == (nw, m, m, F) and S.dtype == torch.complex128
+    assert torch.equal(ff, only)
+    for k in (0, nw // 2, nw - 1):
+        wk = x[:, pos[k]:pos[k] + w]
+        assert_parity(S[k].cpu().numpy(), O.multivariate_spectra(wk, freqs, 500.0, p), 1e-8)
+        assert_parity(ff[k].cpu().numpy(), O.full_freq_dtf(wk, freqs, 500.0, p), 1e-8)
+
+
 def test_multi_dyad_batch_matches_single_dyad_runs():
     """Config 3 in miniature: several dyads in one batch (dyad x window items, forced into several chunks)
     give bit-identical results to running each dyad alone -- the property dyad-sharding across GPUs relies on."""
