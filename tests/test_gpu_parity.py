@@ -500,6 +500,36 @@ def test_ffdtf_and_spectra_of_every_window_from_one_fit(m, n, p, F, nw, chunk):
         assert_parity(ff[k].cpu().numpy(), O.full_freq_dtf(wk, freqs, 500.0, p), 1e-8)
 
 
+def test_in_kernel_normalisation_with_changing_data_in_the_same_workspace():
+    """The row workers of the in-K3 normalisation read |H|^2 that OTHER workgroups wrote earlier in the same launch,
+    without an acquire fence (write-through stores, device-scope flag, non-temporal loads of lines read once per
+    launch).  A stale cache line from an EARLIER launch or chunk would go unnoticed if that launch had written the
+    same values -- so here consecutive launches and consecutive chunks reuse the same workspace addresses with
+    DIFFERENT recordings, in both orders, and every result must equal the separate-pass path bit for bit."""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    T, w, p = 20_000, 1000, 8
+    freqs = northstar_freqs(64)
+    xs = [synthetic_var_dyad(d, T=T) for d in (40, 41, 42)]
+    pos, w = window_positions(T, 2 * T // w - 1, w)                       # 39 windows: 15 normalised in-kernel
+    rec, st = window_items(1, pos, eng.device)
+    xd = [eng.to_device(x[None]) for x in xs]
+    ref = [eng.sliding_ffdtf(d, rec, st, w, p, freqs, 500.0, flags=_lib.FLAG_UNFUSED_NORM).clone() for d in xd]
+    for order in ((0, 1, 2), (2, 0, 1), (1, 1, 0), (0, 2, 2)):
+        got = [eng.sliding_ffdtf(xd[k], rec, st, w, p, freqs, 500.0) for k in order]     # back to back, one stream
+        torch.cuda.synchronize()
+        for k, g in zip(order, got):
+            assert torch.equal(g, ref[k])
+    # three recordings in one call, chunks of one recording each: the workspace is rewritten per chunk
+    x3 = eng.to_device(np.stack(xs))
+    rec3, st3 = window_items(3, pos, eng.device)
+    both = eng.sliding_ffdtf(x3, rec3, st3, w, p, freqs, 500.0, chunk=len(pos))
+    torch.cuda.synchronize()
+    assert torch.equal(both.view(3, len(pos), 64, 64, 64), torch.stack(ref))
+    assert not torch.equal(ref[0], ref[1])
+
+
 def test_multi_dyad_batch_matches_single_dyad_runs():
     """Config 3 in miniature: several dyads in one batch (dyad x window items, forced into several chunks)
     give bit-identical results to running each dyad alone -- the property dyad-sharding across GPUs relies on."""
