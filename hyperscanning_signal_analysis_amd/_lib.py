@@ -40,6 +40,8 @@ SIGNATURES = {
     "hmv_trial_mean_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "hmv_ddtf_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hmv_band_sums_f64": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "hmv_dpss_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "hmv_dpss_f64": (c_int, [c_int64, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "hmv_psd_workspace_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "hmv_psd_multitaper_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64,
                                        c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

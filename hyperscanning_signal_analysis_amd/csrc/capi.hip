@@ -227,6 +227,25 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
   return rc;
 }
 
+int64_t hmv_dpss_workspace_bytes(int64_t n_times, int k_max, int sym) {
+  if (n_times < 2 || k_max < 1 || k_max > n_times) return -1;
+  return (int64_t)hmv::dpss_workspace_bytes(n_times, k_max, sym != 0);
+}
+
+int hmv_dpss_f64(int64_t n_times, double half_nbw, int k_max, int sym, double* tapers, double* ratios, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  if (!tapers || !workspace) return fail(-4, "hmv_dpss_f64: null pointer");
+  if (n_times < 2 || n_times > 0x3fffffff || k_max < 1 || k_max > n_times)
+    return fail(-2, "hmv_dpss_f64: bad size");
+  if (!(half_nbw > 0.0) || half_nbw >= 0.5 * (double)n_times)
+    return fail(-3, "hmv_dpss_f64: the time-half-bandwidth product must lie in (0, n_times / 2)");
+  if (workspace_bytes < hmv::dpss_workspace_bytes(n_times, k_max, sym != 0)) return fail(-7, "hmv_dpss_f64: workspace too small");
+  const int rc = hmv::launch_dpss(n_times, half_nbw, k_max, sym != 0, tapers, ratios, workspace, S(stream));
+  if (rc <= -20) return fail(rc, "hmv_dpss_f64: hipFFT plan / execution failed");
+  if (rc < 0) return fail(rc, "hmv_dpss_f64: bad argument");
+  return rc;
+}
+
 // ---- K3 with the ffDTF normalisation folded in ------------------------------------------------------
 namespace {
 struct TfFfWs {

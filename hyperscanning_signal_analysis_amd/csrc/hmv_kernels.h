@@ -121,4 +121,8 @@ long long psd_workspace_bytes(long long ch_chunk, long long n, int K);
 int launch_psd(const double* x, long long n_ch, long long n, long long ld, const double* tapers, const double* w, int K,
                long long lo, long long hi, double* psd, void* workspace, long long ch_chunk, hipStream_t st);
 
+// ---- DPSS tapers (dpss.hip; hipFFT for the concentration ratios) -------------------------------------------------
+long long dpss_workspace_bytes(long long M, int K, int sym);
+int launch_dpss(long long M, double NW, int K, int sym, double* tapers, double* ratios, void* workspace, hipStream_t st);
+
 }  // namespace hmv

@@ -2,14 +2,13 @@
 
 PARITY UNPINNED: the reference delegates to mne==1.11.0 (`psd_array_multitaper`), which is not available
 offline; the kernel path restates that algorithm with mne's defaults (see include/hypermvar.h,
-`hmv_psd_multitaper_f64`, and oracle/psd_oracle.py).  DPSS tapers are computed on the host by SciPy (what mne
-itself calls) and cached per (n_times, time-half-bandwidth) in memory and on disk; everything per sample runs on
-the device:
+`hmv_psd_multitaper_f64`, and oracle/psd_oracle.py).  The DPSS tapers come from the device too (`hmv_dpss_f64`: the
+algorithm of scipy.signal.windows.dpss, which mne calls, restated for the GPU) and are cached per (n_times,
+time-half-bandwidth) in memory and on disk; everything per sample runs on the device:
 taper products, batched real-to-complex FFTs (hipFFT) and the eigenvalue-weighted power sum.
 """
 from __future__ import annotations
 
-import functools
 import os
 import tempfile
 
@@ -19,7 +18,7 @@ import torch
 from . import _lib
 from .engine import default_engine
 
-__all__ = ["compute_psd_multitaper", "average_psd_across_conditions"]
+__all__ = ["compute_psd_multitaper", "average_psd_across_conditions", "dpss_device"]
 
 
 def _taper_cache_dir():
@@ -30,12 +29,35 @@ def _taper_cache_dir():
     return d or os.path.join(tempfile.gettempdir(), "hypermvar_dpss")
 
 
-@functools.lru_cache(maxsize=8)
-def _tapers(n_times: int, half_nbw: float):
-    """(tapers (K, n_times), sqrt(eigenvalues)) as mne selects them (low_bias: eigenvalue > 0.9).  SciPy's DPSS is the
-    host-bound part of the PSD leg (55 s for a 220 s segment at 500 Hz, 438 tapers, against 76 ms on the GPU for the
-    whole PSD), and a batch meets the same (length, bandwidth) again and again: the tapers are cached in memory per
-    process and on disk across processes and ranks (plain .npz, written atomically)."""
+def dpss_device(n_times: int, half_nbw: float, k_max: int, sym: bool = False, engine=None):
+    """(tapers (k_max, n_times), concentration ratios (k_max,)) as device tensors: scipy.signal.windows.dpss(n_times,
+    half_nbw, k_max, sym=sym, norm=2, return_ratios=True) computed on the GPU (`hmv_dpss_f64`)."""
+    eng = engine or default_engine()
+    nbytes = int(eng.lib.hmv_dpss_workspace_bytes(int(n_times), int(k_max), int(bool(sym))))
+    if nbytes < 0:
+        raise ValueError("dpss: bad n_times / k_max")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+    tapers = eng.empty(int(k_max), int(n_times))
+    ratios = eng.empty(int(k_max))
+    with torch.cuda.device(eng.device):
+        rc = eng.lib.hmv_dpss_f64(int(n_times), float(half_nbw), int(k_max), int(bool(sym)), tapers.data_ptr(), ratios.data_ptr(),
+                                  ws.data_ptr(), nbytes, eng.stream())
+    _lib.check(rc, "hmv_dpss_f64")
+    return tapers, ratios
+
+
+_TAPERS = {}        # (device, n_times, half_nbw) -> (tapers, weights) on that device
+
+
+def _tapers(n_times: int, half_nbw: float, eng):
+    """(tapers (K, n_times), sqrt(eigenvalues)) on the engine's device, as mne selects them (low_bias: eigenvalue > 0.9).
+    A batch meets the same (length, bandwidth) again and again: cached in memory per process and on disk across
+    processes and ranks (plain .npz, written atomically); computed on the GPU otherwise (SciPy's host DPSS costs 55 s
+    for a 220 s segment at 500 Hz)."""
+    key = (str(eng.device), int(n_times), float(half_nbw))
+    hit = _TAPERS.get(key)
+    if hit is not None:
+        return hit
     path = None
     cdir = _taper_cache_dir()
     if cdir is not None:
@@ -43,28 +65,33 @@ def _tapers(n_times: int, half_nbw: float):
         if os.path.exists(path):
             try:
                 with np.load(path, allow_pickle=False) as z:
-                    return np.ascontiguousarray(z["tapers"]), np.ascontiguousarray(z["weights"])
+                    out = (eng.to_device(z["tapers"]), eng.to_device(z["weights"]))
+                    _TAPERS[key] = out
+                    return out
             except Exception:          # unreadable or half-written file: recompute
                 pass
-    from scipy.signal.windows import dpss
     k_max = max(int(2 * half_nbw), 1)
-    tapers, eig = dpss(n_times, half_nbw, k_max, sym=False, norm=2, return_ratios=True)
-    tapers, eig = np.atleast_2d(tapers), np.atleast_1d(eig)
-    idx = eig > 0.9                                    # low_bias=True
-    if not idx.any():
-        idx = np.zeros_like(idx)
-        idx[np.argmax(eig)] = True
-    tapers, weights = np.ascontiguousarray(tapers[idx]), np.sqrt(eig[idx])
+    tapers, eig = dpss_device(n_times, half_nbw, k_max, False, eng)
+    eig_h = eig.cpu().numpy()                          # k_max numbers: selection and weights on the host
+    keep = eig_h > 0.9                                 # low_bias=True
+    if not keep.any():
+        keep = np.zeros_like(keep)
+        keep[np.argmax(eig_h)] = True
+    idx = torch.as_tensor(np.flatnonzero(keep)).to(eng.device)
+    out = (tapers.index_select(0, idx).contiguous(), eng.to_device(np.sqrt(eig_h[keep])))
+    if len(_TAPERS) >= 8:
+        _TAPERS.pop(next(iter(_TAPERS)))
+    _TAPERS[key] = out
     if path is not None:
         try:
             os.makedirs(cdir, exist_ok=True)
             tmp = f"{path}.{os.getpid()}.tmp"
             with open(tmp, "wb") as f:
-                np.savez(f, tapers=tapers, weights=weights)
+                np.savez(f, tapers=out[0].cpu().numpy(), weights=out[1].cpu().numpy())
             os.replace(tmp, path)
         except OSError:                # read-only or full disk: the cache is an optimisation only
             pass
-    return tapers, weights
+    return out
 
 
 def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30, engine=None):
@@ -75,8 +102,8 @@ def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_byt
         raise ValueError("data must have shape (n_channels, n_times)")
     n_ch, n_times = x.shape
     half_nbw = float(bandwidth) * n_times / (2.0 * float(sfreq))
-    tapers, w = _tapers(n_times, half_nbw)
-    K = tapers.shape[0]
+    td, wd = _tapers(n_times, half_nbw, eng)
+    K = td.shape[0]
     freqs = np.fft.rfftfreq(n_times, 1.0 / float(sfreq))
     sel = np.flatnonzero((freqs >= fmin) & (freqs <= fmax))
     if sel.size == 0:
@@ -86,7 +113,7 @@ def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_byt
     ch_chunk = int(max(1, min(n_ch, max_workspace_bytes // max(per_ch, 1))))
     nbytes = int(eng.lib.hmv_psd_workspace_bytes(ch_chunk, n_times, K))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
-    xd, td, wd = eng.to_device(x), eng.to_device(tapers), eng.to_device(w)
+    xd = eng.to_device(x)
     out = eng.empty(n_ch, hi - lo + 1)
     with torch.cuda.device(eng.device):
         rc = eng.lib.hmv_psd_multitaper_f64(xd.data_ptr(), n_ch, n_times, n_times, td.data_ptr(), wd.data_ptr(), K,

@@ -133,9 +133,19 @@ int hmv_band_sums_f64(const double* ffdtf, int64_t n_rows, int F, const int32_t*
  * (remove_dc, non-adaptive eigenvalue weights, normalization "length").  mne is NOT available offline: PARITY
  * UNPINNED -- the algorithm is restated from its published description and checked against an independent
  * NumPy restatement only.  x: [n_ch][ld] (n_times samples used), tapers: [n_tapers][n_times] DPSS windows and
- * weights[k] = sqrt(eigenvalue_k) from the host (scipy.signal.windows.dpss), bins bin_lo..bin_hi of the
+ * weights[k] = sqrt(eigenvalue_k) (hmv_dpss_f64, or scipy.signal.windows.dpss on the host), bins bin_lo..bin_hi of the
  * one-sided spectrum (freq = bin * sfreq / n_times); psd: [n_ch][bin_hi - bin_lo + 1].  Transforms by hipFFT;
  * plans are cached per (n_times, batch).  workspace: hmv_psd_workspace_bytes(ch_chunk, n_times, n_tapers). */
+/* DPSS (Slepian) tapers and their concentration ratios on the device: what scipy.signal.windows.dpss(n_times, half_nbw,
+ * k_max, sym=bool(sym), norm=2, return_ratios=True) returns (mne's taper generator calls it with sym=False: the symmetric
+ * window of n_times + 1 points without its last sample), by the same algorithm -- the k_max largest
+ * eigenpairs of the commuting symmetric tridiagonal matrix by Sturm-count multisection and inverse iteration (LAPACK
+ * dstebz / dstein restated), SciPy's sign convention, ratios through hipFFT.  tapers: [k_max][n_times], ratios (optional):
+ * [k_max].  Agrees with SciPy to ~1e-10 (tests/test_psd.py); PARITY UNPINNED like the PSD itself.  The call synchronises
+ * `stream` once when ratios are requested (the FFT plan is created and destroyed inside). */
+int64_t hmv_dpss_workspace_bytes(int64_t n_times, int k_max, int sym);
+int hmv_dpss_f64(int64_t n_times, double half_nbw, int k_max, int sym, double* tapers, double* ratios,
+                 void* workspace, int64_t workspace_bytes, void* stream);
 int64_t hmv_psd_workspace_bytes(int64_t ch_chunk, int64_t n_times, int n_tapers);
 int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64_t ld, const double* tapers,
                            const double* weights, int n_tapers, int64_t bin_lo, int64_t bin_hi, double* psd,

@@ -21,6 +21,7 @@ for args in ((1, 64, 8, 256), (599, 64, 8, 256), (0, 64, 8, 256), (5, 65, 8, 256
 lib.hmv_tf_workspace_doubles(10, 64, 8); lib.hmv_tf_workspace_doubles(-1, 64, 8); lib.hmv_psd_workspace_bytes(4, 1000, 7)
 lib.hmv_lagcov_regular_workspace_doubles(599, 64, 1000, 500, 8); lib.hmv_lagcov_regular_workspace_doubles(5, 64, 1000, 300, 8)
 lib.hmv_psd_workspace_bytes(0, 1, 0)
+assert lib.hmv_dpss_workspace_bytes(1000, 8, 0) > 0 and lib.hmv_dpss_workspace_bytes(1, 1, 0) < 0 and lib.hmv_dpss_workspace_bytes(10, 11, 1) < 0
 bad = [
     lib.hmv_lagcov_f64(D, 0, 0, D, D, 1, 65, 100, 4, D, 0),
     lib.hmv_lagcov_f64(D, 0, 0, D, D, 1, 4, 100, 40, D, 0),
@@ -55,6 +56,10 @@ bad = [
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 900, D, D, 3, 1, 100, D, D, 1 << 30, 4, 0),
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 1000, D, D, 3, 1, 600, D, D, 1 << 30, 4, 0),
     lib.hmv_psd_multitaper_f64(D, 4, 1000, 1000, D, D, 3, 1, 100, D, D, 8, 4, 0),
+    lib.hmv_dpss_f64(1000, 4.0, 8, 0, 0, D, D, 1 << 40, 0),
+    lib.hmv_dpss_f64(1000, 4.0, 1001, 0, D, D, D, 1 << 40, 0),
+    lib.hmv_dpss_f64(1000, 500.0, 8, 0, D, D, D, 1 << 40, 0),
+    lib.hmv_dpss_f64(1000, 4.0, 8, 1, D, D, D, 64, 0),
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 65, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 64, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, 0, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
