@@ -292,11 +292,13 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         re[Ig][Jl] = (16 * Ig + rowl == 4 * NT * Jl + colw) ? 1.0 : 0.0;
         im[Ig][Jl] = 0.0;
       }
-    // Chunks of HC lag pairs; a batch (two column blocks of one row group) issues all of its loads before
-    // the first FMA (explicit staging array + sched_barrier: left alone the compiler serialises every load
-    // behind an s_waitcnt).
+    // Chunks of HC lag pairs.  The loads roll: DEPTH register blocks' worth (DEPTH * HC 16-byte loads per lane) are in
+    // flight while one block is consumed -- the coefficients come out of the XCD's L2 at ~2000 cycles per round trip
+    // with every CU pulling, and a round trip per batch of 8 loads was 12.7 % of a wave's life (tools/k3_stamps.py).
+    // Explicit staging + sched_barrier: left alone the compiler serialises every load behind an s_waitcnt.
     auto chunk = [&](auto hc_tag, int h0) __attribute__((always_inline)) {
       constexpr int HC = decltype(hc_tag)::value;
+      constexpr int NB = NG * 4, DEPTH = (HC == 4) ? 3 : 8;       // 12 (HC = 4) or 8 (HC = 1) loads in flight
       double zr[2 * HC], zi[2 * HC];
 #pragma unroll
       for (int k = 0; k < 2 * HC; ++k) {
@@ -304,29 +306,29 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfAr
         zr[k] = (lag < p) ? tw[2 * lag] : 0.0;
         zi[k] = (lag < p) ? tw[2 * lag + 1] : 0.0;
       }
-      static_for<NG * 2>([&](auto bc) __attribute__((always_inline)) {
-        constexpr int Ig = decltype(bc)::value >> 1, J0 = 2 * (decltype(bc)::value & 1);
-        double2 v[2][HC];
+      double2 v[DEPTH][HC];
+      auto issue = [&](auto bc) __attribute__((always_inline)) {
+        constexpr int B = decltype(bc)::value;
+        const double2* e = ax + ((size_t)(B * P2 + h0)) * 64;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const double2* e = ax + ((size_t)((Ig * 4 + J0 + d) * P2 + h0)) * 64;
-#pragma unroll
-          for (int h = 0; h < HC; ++h) v[d][h] = e[h * 64];
-        }
+        for (int h = 0; h < HC; ++h) v[B % DEPTH][h] = e[h * 64];
+      };
+      static_for<(DEPTH < NB ? DEPTH : NB)>([&](auto bc) __attribute__((always_inline)) { issue(bc); });
+      static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int B = decltype(bc)::value, Ig = B >> 2, Jl = B & 3;
         __builtin_amdgcn_sched_barrier(0);
+        double sr = re[Ig][Jl], si = im[Ig][Jl];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          double sr = re[Ig][J0 + d], si = im[Ig][J0 + d];
-#pragma unroll
-          for (int h = 0; h < HC; ++h) {
-            sr = __builtin_fma(-v[d][h].x, zr[2 * h], sr);
-            si = __builtin_fma(-v[d][h].x, zi[2 * h], si);
-            sr = __builtin_fma(-v[d][h].y, zr[2 * h + 1], sr);
-            si = __builtin_fma(-v[d][h].y, zi[2 * h + 1], si);
-          }
-          re[Ig][J0 + d] = sr;
-          im[Ig][J0 + d] = si;
+        for (int h = 0; h < HC; ++h) {
+          sr = __builtin_fma(-v[B % DEPTH][h].x, zr[2 * h], sr);
+          si = __builtin_fma(-v[B % DEPTH][h].x, zi[2 * h], si);
+          sr = __builtin_fma(-v[B % DEPTH][h].y, zr[2 * h + 1], sr);
+          si = __builtin_fma(-v[B % DEPTH][h].y, zi[2 * h + 1], si);
         }
+        re[Ig][Jl] = sr;
+        im[Ig][Jl] = si;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (B + DEPTH < NB) issue(std::integral_constant<int, B + DEPTH>{});
       });
     };
     int h0 = 0;

@@ -19,8 +19,10 @@
 //
 // Two forms walk the same tile products in the same order (bit-identical results):
 //   * tile form: one workgroup (4 waves) per (window, tile); the factorisation is launched tile column by tile
-//     column (diagonal tile kernel, then all tiles below it), so a batch of a few hundred windows still fills the
-//     chip; the back substitution and the emit are one more launch with one workgroup per window;
+//     column (the diagonal tile and all tiles below it in ONE launch: the scaling Lt = Y D^-1 of a column is deferred
+//     to the next column's launch, so nothing inside a launch waits for the diagonal tile's inverse), so a batch of
+//     a few hundred windows still fills the chip; the back substitution and the emit are one more launch with one
+//     workgroup per window;
 //   * window form (yw_window_kernel): one workgroup per window does everything in one launch.
 // Every tile product is an MP x MP x MP real GEMM on v_mfma_f64_4x4x4_4b_f64 with both operands staged in LDS (row
 // stride 6 mod 32 doubles: conflict-free A- and B-operand reads); wave w owns row blocks w*NT .. w*NT+NT-1 of the
@@ -165,9 +167,9 @@ __device__ __forceinline__ YwPtrs yw_ptrs(const YwArgs& a, long long item) {
 // ---- the kernel of both forms ---------------------------------------------------------------------------------
 // Window form (MODE 0): one workgroup walks the whole left-looking schedule of its window in ONE launch, with the
 // scratch tiles in global memory (private to the workgroup: only workgroup barriers order them).  Tile form: the same
-// kernel body per tile -- MODE 3 one diagonal tile, MODE 2 one off-diagonal tile per workgroup, launched tile column
-// by tile column, then MODE 1 (back substitution + emit, one workgroup per window): 18 launches per batch (round 1:
-// ~50), each filling the chip.  Same tile products in the same order either way: bit-identical results.
+// kernel body per tile -- MODE 2 one tile (diagonal or not) of one tile column per workgroup, launched tile column by
+// tile column, then MODE 1 (back substitution + emit, one workgroup per window): p + 2 = 10 launches per batch (round 1:
+// ~50; round 2a: 18), each filling the chip.  Same tile products in the same order either way: bit-identical results.
 // Operands are staged through LDS in two k-halves (39 KB + the inverse's panels: four column-tile workgroups or three
 // window workgroups per CU; round 1 staged whole tiles, 72-78 KB, two per CU), the second half's loads in flight
 // behind the first half's MFMAs.
@@ -183,11 +185,10 @@ struct YwWin {
 // VQ: also the residual covariances of the lower orders (log det V_q, model-order criterion) -- its own
 // instantiation because the extra tile and inverse do not fit the 168 registers that three workgroups per CU allow.
 // MODE 0: the whole window.  MODE 1 (tile launch chain): only the back substitution and the emit, one launch instead
-// of the p - 1 pivot-block launches + 2 emit launches of round 1.  MODE 2 (tile launch chain): ONE off-diagonal tile
-// (ta, tb_arg) of one window per workgroup -- the column kernel of the chain with this kernel's k-half staging
-// (39 KB of LDS, 98 VGPRs: four workgroups per CU instead of the two of round 1's whole-tile column kernel, and the
-// second k-half's loads in flight behind the first half's MFMAs: 127 -> 114 us per launch).  MODE 3: ONE diagonal tile
-// (tb_arg) per workgroup, the diagonal kernel of the chain, likewise.
+// of the p - 1 pivot-block launches + 2 emit launches of round 1.  MODE 2 (tile launch chain): ONE tile (ta, tb_arg),
+// ta >= tb_arg, of one window per workgroup with this kernel's k-half staging (39 KB of LDS: four workgroups per CU
+// instead of the two of round 1's whole-tile column kernel, and the second k-half's loads in flight behind the first
+// half's MFMAs).
 template <int NT, bool VQ, int MODE = 0>
 __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, int tb_arg) {
   constexpr bool BACK_ONLY = (MODE == 1);
@@ -205,13 +206,13 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, in
   long long item = blockIdx.x;
   int ta_col = 0;
   if (MODE == 2) {
-    // XCD-aware block -> (window, tile) map: the p - tb tiles of one window read the same tb tiles Y[tb][c] and the
-    // same D_tb^-1; blocks b and b + 8 share an XCD (and its L2), so the tiles of a window sit 8 blocks apart.
-    const unsigned ntile = (unsigned)(p - tb_arg);
+    // XCD-aware block -> (window, tile) map: the p - tb + 1 tiles of one window read the same tb tiles Y[tb][c] and
+    // the same D^-1; blocks b and b + 8 share an XCD (and its L2), so the tiles of a window sit 8 blocks apart.
+    const unsigned ntile = (unsigned)(p - tb_arg + 1);
     const unsigned grp = blockIdx.x / (8u * ntile), r = blockIdx.x - grp * (8u * ntile);
     item = (long long)grp * 8 + (r & 7u);
     if (item >= a.n_items) return;                       // padding of the last group (whole workgroup)
-    ta_col = tb_arg + 1 + (int)(r >> 3);
+    ta_col = tb_arg + (int)(r >> 3);                     // the diagonal tile first
   }
   const YwPtrs q = yw_ptrs<MP>(a, item);
   if (threadIdx.x == 0) s_info = 0;
@@ -358,24 +359,52 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, in
 
   double g[NIW][NJ], acc[NIW][NJ];
   const double (&none)[NIW][NJ] = g;
-  if (MODE == 2) {                     // Y = G - sum_c Lt[ta][c] Y[tb][c]^T ; Lt = Y D^-1   
+  if (MODE == 2) {
+    // One tile (ta, tb), ta >= tb, of tile column tb.  Nothing in a launch depends on anything else in it: the scaling
+    // by the pivot block's inverse, Lt[ta][tb-1] = Y[ta][tb-1] D_{tb-1}^-1, is deferred to the workgroup that first
+    // needs it -- this one, one launch later -- so the diagonal tile (its product sum and its inversion) runs beside
+    // the tiles below it instead of in a launch of its own between two column launches (round 2a: 18 launches, the
+    // nine diagonal ones with one workgroup per window, a third of the chain's time).
     const int tb = tb_arg, ta = ta_col;
-    zero(acc);
-    for (int c = 0; c < tb; ++c)
-      product(acc, q.Lt + yw_tri(ta, c) * TILE, none, q.Yt + yw_tri(tb, c) * TILE, false);
+    if (tb > 0) {
+      load_tile(g, q.Yt + yw_tri(ta, tb - 1) * TILE);
+      zero(acc);
+      product(acc, nullptr, g, q.Dinv + (size_t)(tb - 1) * TILE, true);
+      store_tile(q.Lt + yw_tri(ta, tb - 1) * TILE, acc);
+      if (ta == p) store_tile(q.Zt + (size_t)(tb - 1) * TILE, acc);      // start value of the back substitution
+      __syncthreads();                 // ... and operand of this workgroup's last product below
+    }
     load_G(g, ta, tb);
+    zero(acc);
+    for (int c = 0; c < tb; ++c) {
+      product(acc, q.Lt + yw_tri(ta, c) * TILE, none, q.Yt + yw_tri(tb, c) * TILE, false);
+      if (VQ && ta == p && tb == p) {   // V_{c+1}: residual covariance of order c+1 (model-order criterion)
+        double vq[NIW][NJ];
+#pragma unroll
+        for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+          for (int J = 0; J < NJ; ++J) vq[ii][J] = g[ii][J] - acc[ii][J];
+        tile_to_lds(vq);
+        spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, nullptr, a.Vq_logdet + (size_t)item * p + c, tb * MP);
+      }
+    }
 #pragma unroll
     for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
       for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
-    store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
-    zero(acc);
-    product(acc, nullptr, g, q.Dinv + (size_t)tb * TILE, true);
-    store_tile(q.Lt + yw_tri(ta, tb) * TILE, acc);
-    if (ta == p) store_tile(q.Zt + (size_t)tb * TILE, acc);      // start value of the back substitution
+    if (ta != tb) {
+      store_tile(q.Yt + yw_tri(ta, tb) * TILE, g);
+    } else if (tb == p) {
+      store_tile(a.V + (size_t)item * TILE, g);
+    } else {
+      tile_to_lds(g);
+      spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
+      __syncthreads();
+      if (threadIdx.x == 0 && s_info != 0) atomicCAS(&a.info[item], 0, s_info);
+    }
     return;
   }
-  for (int tb = (MODE == 3 ? tb_arg : 0); tb <= (BACK_ONLY ? -1 : (MODE == 3 ? tb_arg : p)); ++tb) {
+  for (int tb = 0; tb <= (BACK_ONLY ? -1 : p); ++tb) {
     // ---- diagonal tile: D = G[tb][tb] - sum_c Lt[tb][c] Y[tb][c]^T ; D^-1 (tb < p) or V (tb == p)
     load_G(g, tb, tb);
     zero(acc);
@@ -397,16 +426,11 @@ __global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, in
       for (int J = 0; J < NJ; ++J) g[ii][J] -= acc[ii][J];
     if (tb == p) {
       store_tile(a.V + (size_t)item * TILE, g);
-      if (MODE == 3) return;
       break;
     }
     tile_to_lds(g);
     spd_inverse_coop<NT, SI>(buf, Pb, Nb, &s_info, s_ld, q.Dinv + (size_t)tb * TILE, nullptr, tb * MP);
     __syncthreads();                   // D^-1 is in global memory for the whole workgroup
-    if (MODE == 3) {                   // tile launch chain: the column tiles are the next launch
-      if (threadIdx.x == 0 && s_info != 0) atomicCAS(&a.info[item], 0, s_info);
-      return;
-    }
     // ---- tiles below it: Y = G - sum_c Lt[ta][c] Y[tb][c]^T ; Lt = Y D^-1
     for (int ta = tb + 1; ta <= p; ++ta) {
       load_G(g, ta, tb);
@@ -458,11 +482,10 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   const int p = a.p;
   const unsigned n = (unsigned)a.n_items;
   (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
-  for (int tb = 0; tb <= p; ++tb) {
-    if (a.Vq_logdet && tb == p) hipLaunchKernelGGL((yw_window_kernel<NT, true, 3>), dim3(n), dim3(256), 0, st, a, tb);
-    else hipLaunchKernelGGL((yw_window_kernel<NT, false, 3>), dim3(n), dim3(256), 0, st, a, tb);
-    if (tb < p)
-      hipLaunchKernelGGL((yw_window_kernel<NT, false, 2>), dim3(((n + 7) / 8) * 8 * (p - tb)), dim3(256), 0, st, a, tb);
+  for (int tb = 0; tb <= p; ++tb) {          // tile column tb: p - tb + 1 tiles per window, the diagonal one included
+    const dim3 grid(((n + 7) / 8) * 8 * (unsigned)(p - tb + 1));
+    if (a.Vq_logdet && tb == p) hipLaunchKernelGGL((yw_window_kernel<NT, true, 2>), grid, dim3(256), 0, st, a, tb);
+    else hipLaunchKernelGGL((yw_window_kernel<NT, false, 2>), grid, dim3(256), 0, st, a, tb);
   }
   // back substitution + emit: one workgroup per window, one launch (round 1: p - 1 pivot-block launches, each
   // re-reading and re-writing the Z tiles it updates, then two emit launches)
