@@ -190,13 +190,19 @@ struct YwWin {
 // instead of the two of round 1's whole-tile column kernel, and the second k-half's loads in flight behind the first
 // half's MFMAs).
 template <int NT, bool VQ, int MODE = 0>
-__global__ void __launch_bounds__(256, VQ ? 2 : 3) yw_window_kernel(YwArgs a, int tb_arg) {
+__global__ void __launch_bounds__(256, VQ ? 2 : (MODE == 2 ? 4 : 3)) yw_window_kernel(YwArgs a, int tb_arg) {
   constexpr bool BACK_ONLY = (MODE == 1);
   using W = YwWin<NT>;
-  constexpr int MP = W::MP, KH = W::KH, SH = W::SH, NIW = NT, NJ = NT, TILE = W::TILE, NV = W::NV, SI = W::SI;
+  constexpr int MP = W::MP, KH = W::KH, SH = W::SH, NIW = NT, NJ = NT, TILE = W::TILE, NV = W::NV;
+  // The tile kernel (MODE 2) keeps the inverse's image unpadded (read once per inversion: its bank conflicts are
+  // noise) with the panel buffers behind it, inside the operand block: 39 KB in all, four workgroups per CU.
+  constexpr bool PACKED = (MODE == 2) && !VQ && (MP * MP + 12 * MP <= W::BUF_D);
+  constexpr int SI = PACKED ? MP : W::SI;
   __shared__ __attribute__((aligned(16))) double buf[W::BUF_D];
-  __shared__ double Pb[MP * 4];
-  __shared__ double Nb[2 * MP * 4];
+  __shared__ double Pb_[PACKED ? 1 : MP * 4];
+  __shared__ double Nb_[PACKED ? 1 : 2 * MP * 4];
+  double* Pb = PACKED ? buf + MP * MP : Pb_;
+  double* Nb = PACKED ? buf + MP * MP + 4 * MP : Nb_;
   __shared__ int s_info;
   __shared__ double s_ld[4];
   double* Xh = buf;                 // [MP][SH]  k-half of the A-operand tile
