@@ -44,6 +44,13 @@
 
 namespace hmv {
 
+// Workgroups per CU of the 64-channel instance: 4 = 128 VGPRs (8 spilled).  5 would need 96: the compiler then spills
+// 1 764 registers (the 64 accumulators + the factorisation's 52 or the update's operands do not fit), measured again
+// in round 2 (profiles/r02_ab_notes.md); kept as a build knob for the next attempt.
+#ifndef HMV_K3_WGS
+#define HMV_K3_WGS 4
+#endif
+
 #define HMV_LDS_FENCE()                                     \
   do {                                                      \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
 // complex matrices Zin[item][f][MP][MP] (partial coherence of a spectral matrix, mtmvar.py:287-338), which
 // also returns the unit-modulus phase of the determinant (product of the pivots, sign of the interchanges).
 template <int NT, bool GEN>
-__global__ void __launch_bounds__(64 * NT, (NT == 4) ? 4 : 2) tf_inv_kernel(TfArgs a) {
+__global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_kernel(TfArgs a) {
   constexpr int MP = 16 * NT, NG = NT, NSTEP = MP / 4;
   using L = TfLds<NT>;
   constexpr int NR = L::NRING;
