@@ -155,7 +155,7 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
 #define HMV_FLAG_UNFUSED_NORM 1   /* ffDTF normalisation as a separate pass over |H|^2 (K4) instead of inside K3 */
 #define HMV_FLAG_DIRECT_LAGCOV 8   /* K1 sums every window from its own samples even on a regular grid (results then do
                                      not depend on how the windows are laid out: bit-identical across grids) */
-#define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in 18 launches (tile column by tile column), and */
+#define HMV_FLAG_YW_TILED 2       /* K2 as one workgroup per tile in p + 2 launches (tile column by tile column), and */
 #define HMV_FLAG_YW_ONE_LAUNCH 4  /* K2 as one workgroup per window in one launch: same tile products in the same
                                      order, same bits.  Neither flag: one launch, except for large 64-channel
                                      batches, where both forms are HBM-bound and the launch chain is faster. */
