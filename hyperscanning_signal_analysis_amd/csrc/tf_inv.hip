@@ -378,12 +378,24 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) x[jj] = Pbuf[r * 5 + jj];
     }
-    int rs[4], bad = 0;      // pivot rows of the four columns, first zero pivot (+1): wave-uniform
+    int rs[4];               // pivot rows of the four columns (wave-uniform)
+    double dds[4];           // |pivot|^2 of the four columns (wave-uniform): zero / NaN pivots are looked for once, below
     double dpr = 1.0, dpi = 0.0;   // GEN: unit-modulus product of this panel's pivots (wave-uniform)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * t + jj;
       const bool valid = (l >= col) && (l < MP);
+      // Every lane keeps its current row in its own Pbuf slot (where the panel arrived: column 0 finds it there), so
+      // the pivot row -- whichever it turns out to be -- is one broadcast read away and nothing on the common path
+      // is exec-masked or branched around (a masked region costs a v_cmp / s_and_saveexec / s_cbranch_execz
+      // sequence, ~40 cycles of the workgroup's critical path per pivot column).
+      if (jj > 0) {
+        if (NT == 4 || l < MP) {
+#pragma unroll
+          for (int j2 = 0; j2 < 4; ++j2) Pbuf[l * 5 + j2] = x[j2];
+        }
+        HMV_LDS_FENCE();
+      }
       // Pivot = arg-max of |re|+|im| (LAPACK izamax metric) over the not-yet-pivoted rows, or the diagonal
       // when it is within tau of the maximum.  Fast path: no row exceeds the diagonal (one compare + ballot;
       // the common case for the A(f) of a stable model).  Otherwise the float-rounded magnitude is a 32-bit
@@ -416,9 +428,11 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
           pr = readlane_f64(x[jj].x, rstar);
           pi = readlane_f64(x[jj].y, rstar);
           reciprocal();
-          if (l == col) {
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) Srow[4 + j2] = x[j2];
+          for (int j2 = 0; j2 < 4; ++j2) {       // the lane that holds the pivot row takes the displaced row (slot col)
+            const double2 cv = Pbuf[col * 5 + j2];
+            x[j2].x = (l == rstar) ? cv.x : x[j2].x;
+            x[j2].y = (l == rstar) ? cv.y : x[j2].y;
           }
           if (l == 0) {
             const int oc = s_orig[col], orr = s_orig[rstar];
@@ -438,24 +452,14 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
         dpr = nr_;
         dpi = ni_;
       }
-      if (l == rstar) {
+      double2 pv[4];                 // the pivot row as it was parked (before any interchange touched the registers)
+      {
+        const double2* prow = Pbuf + uni(rstar) * 5;
 #pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) Srow[j2] = x[j2];
+        for (int j2 = 0; j2 < 4; ++j2) pv[j2] = prow[j2];
       }
       HMV_LDS_FENCE();
-      double2 pv[4];
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2) pv[j2] = Srow[j2];
-      if (__builtin_expect(rstar != col, 0)) {     // uniform: the lane that held the pivot row takes the displaced row
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const double2 cv = Srow[4 + j2];
-          x[j2].x = (l == rstar) ? cv.x : x[j2].x;
-          x[j2].y = (l == rstar) ? cv.y : x[j2].y;
-        }
-      }
-      HMV_LDS_FENCE();
-      if (!(dd > 0.0) && bad == 0) bad = col + 1;      // wave-uniform
+      dds[jj] = dd;
       // Elimination with the per-row multiplier mu = -x_jj / pivot:  x <- x + mu * (pivot row), and column
       // jj becomes mu itself (in-place inverse).  The pivot row's lane takes mu = 1/pivot on a zeroed row,
       // which yields the scaled pivot row and 1/pivot in column jj from the same FMAs: no per-element
@@ -466,6 +470,9 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
       double mi = __builtin_fma(-fr, ivi, -(fi * ivr));
       mr = isp ? ivr : mr;
       mi = isp ? ivi : mi;
+      // (Scaling the pivot row as row + (1/pivot - 1) * row would save the zeroed copy -- 5 instructions per column --
+      // and was measured 0.1 ms SLOWER: the six multiplications are independent work that holds the issue port between
+      // the dependent steps of the chain, profiles/r02_ab_notes.md.)
       const double keep = isp ? 0.0 : 1.0;
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
@@ -477,13 +484,20 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
       x[jj].x = mr;
       x[jj].y = mi;
     }
-    if (l < MP) {
+    if (NT == 4 || l < MP) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) Nout[l * 4 + jj] = x[jj];
     }
+    // zero (or NaN) pivot: one test for the panel on the common path, the column is worked out only if it fails
+    const bool all_ok = (dds[0] > 0.0) && (dds[1] > 0.0) && (dds[2] > 0.0) && (dds[3] > 0.0);
     if (l == 0) {
-      *reinterpret_cast<int4*>(&s_swp[t % NR][0]) = make_int4(rs[0], rs[1], rs[2], rs[3]);
-      if (bad != 0 && s_info == 0) s_info = bad;
+      // interchange list as row distances (0 = none): the other waves test the four of them with one OR
+      *reinterpret_cast<int4*>(&s_swp[t % NR][0]) =
+          make_int4(rs[0] - 4 * t, rs[1] - (4 * t + 1), rs[2] - (4 * t + 2), rs[3] - (4 * t + 3));
+      if (__builtin_expect(!all_ok, 0)) {
+        const int bad = !(dds[0] > 0.0) ? 4 * t + 1 : (!(dds[1] > 0.0) ? 4 * t + 2 : (!(dds[2] > 0.0) ? 4 * t + 3 : 4 * t + 4));
+        if (s_info == 0) s_info = bad;
+      }
       if constexpr (GEN) {
         const double qr = s_det[0], qi = s_det[1];
         s_det[0] = __builtin_fma(qr, dpr, -(qi * dpi));
@@ -528,8 +542,9 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
   // Row interchanges of step t on this wave's 16 columns (rare; through LDS).
   auto interchange = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value, Igp = t >> 2, bp = t & 3;
-    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[t % NR][0]);
-    const int swr[4] = {uni(swv.x), uni(swv.y), uni(swv.z), uni(swv.w)};
+    const int4 swv = *reinterpret_cast<const int4*>(&s_swp[t % NR][0]);      // row distances, 0 = no interchange
+    if (__builtin_expect(uni(swv.x | swv.y | swv.z | swv.w) == 0, 1)) return;   // one branch on the common path
+    const int swr[4] = {uni(swv.x) + 4 * t, uni(swv.y) + 4 * t + 1, uni(swv.z) + 4 * t + 2, uni(swv.w) + 4 * t + 3};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int col = 4 * t + jj;
