@@ -61,7 +61,7 @@ def test_gpu_psd_chunked_channels_and_edges():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sym", [False, True])
-@pytest.mark.parametrize("M,NW,K", [(64, 2.0, 4), (1000, 4.0, 8), (999, 2.5, 5), (4096, 8.0, 16), (6000, 12.0, 24), (20_000, 40.0, 80)])
+@pytest.mark.parametrize("M,NW,K", [(16, 1.5, 2), (33, 1.0, 1), (64, 2.0, 4), (1000, 4.0, 8), (999, 2.5, 5), (4096, 8.0, 16), (6000, 12.0, 24), (20_000, 40.0, 80)])
 def test_gpu_dpss_matches_scipy(M, NW, K, sym):
     """`hmv_dpss_f64` (Sturm-count multisection + inverse iteration on the commuting tridiagonal matrix, SciPy's sign
     convention, ratios through hipFFT) against scipy.signal.windows.dpss -- the generator mne calls.  Eigenvectors of
@@ -77,3 +77,24 @@ def test_gpu_dpss_matches_scipy(M, NW, K, sym):
         assert np.abs(t @ t.T - np.eye(K)).max() < 1e-9                           # orthogonal without re-orthogonalisation
     assert np.abs(t - ref_t).max() < 1e-9, np.abs(t - ref_t).max()
     assert np.abs(r - ref_r).max() < 1e-11, np.abs(r - ref_r).max()
+
+
+@pytest.mark.gpu
+def test_gpu_dpss_refuses_bad_arguments_and_psd_uses_device_tapers(tmp_path, monkeypatch):
+    """hmv_dpss_f64 argument checks surface as exceptions; compute_psd_multitaper takes its tapers from the device
+    generator (a taper file appears in the cache directory, and a second call reads it back to the same result)."""
+    from hyperscanning_signal_analysis_amd import psd as P
+    with pytest.raises(Exception):
+        P.dpss_device(100, 60.0, 4)            # half-bandwidth product >= n_times / 2
+    with pytest.raises(Exception):
+        P.dpss_device(100, 4.0, 101)           # more tapers than samples
+    monkeypatch.setenv("HYPERMVAR_DPSS_CACHE", str(tmp_path))
+    P._TAPERS.clear()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3, 1500))
+    f1, p1 = P.compute_psd_multitaper(x, 250.0, 1.0, 40.0, 2.0)
+    files = list(tmp_path.glob("dpss_n1500_*.npz"))
+    assert len(files) == 1
+    P._TAPERS.clear()                          # second call: tapers from the file
+    f2, p2 = P.compute_psd_multitaper(x, 250.0, 1.0, 40.0, 2.0)
+    assert np.array_equal(f1, f2) and np.array_equal(p1, p2)
