@@ -17,6 +17,8 @@ SIGNATURES = {
     "hmv_version": (c_int, []),
     "hmv_last_error": (c_char_p, []),
     "hmv_pad": (c_int, [c_int]),
+    "hmv_set_tuning": (c_int, [c_int, c_int64]),
+    "hmv_get_tuning": (c_int64, [c_int]),
     "hmv_yw_workspace_doubles": (c_int64, [c_int, c_int]),
     "hmv_lagcov_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                c_void_p, c_void_p]),
@@ -60,6 +62,11 @@ FLAG_UNFUSED_NORM = 1
 FLAG_YW_TILED = 2
 FLAG_YW_ONE_LAUNCH = 4
 FLAG_DIRECT_LAGCOV = 8
+# hmv_set_tuning keys
+TUNE_NORM_LAG = 1
+TUNE_LAG_GROUP = 2
+TUNE_K3_FORM = 3
+TUNE_YW_FORM = 4
 
 
 _lib = None

@@ -2,6 +2,7 @@
 #include "../../include/hypermvar.h"
 #include "hmv_kernels.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,30 @@ int fail(int code, const char* msg) {
 int pad_of(int m) { return (m < 1 || m > HMV_MAX_CHANNELS) ? -1 : ((m + 15) / 16) * 16; }
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// Tuning knobs: the environment is parsed once, at load time, with range checks; hmv_set_tuning overrides.
+constexpr int N_TUNE = 5;
+struct TuneRange { long long lo, hi; };
+constexpr TuneRange kTuneRange[N_TUNE] = {{0, 0}, {0, 1 << 20}, {0, 3}, {0, 2}, {0, 2}};
+long long env_knob(const char* name, int key) {
+  const char* e = getenv(name);
+  if (!e || !*e) return 0;
+  char* end = nullptr;
+  const long long v = strtoll(e, &end, 10);
+  if (end == e || *end != 0 || v < kTuneRange[key].lo || v > kTuneRange[key].hi) {
+    fprintf(stderr, "hypermvar: ignoring %s=%s (not an integer in %lld..%lld)\n", name, e, kTuneRange[key].lo,
+            kTuneRange[key].hi);
+    return 0;
+  }
+  return v;
+}
+std::atomic<long long> g_tune[N_TUNE] = {{0}, {env_knob("HYPERMVAR_NORM_LAG", 1)}, {env_knob("HYPERMVAR_LAG_GROUP", 2)},
+                                         {env_knob("HYPERMVAR_K3_FORM", 3)}, {env_knob("HYPERMVAR_YW_FORM", 4)}};
 }  // namespace
+
+namespace hmv {
+long long tuning(int key) { return (key >= 1 && key < N_TUNE) ? g_tune[key].load(std::memory_order_relaxed) : -1; }
+}
 
 #ifdef HMV_STAMP
 // Diagnostic build only (never shipped, not in include/hypermvar.h): where K3 writes its phase stamps.
@@ -29,6 +53,14 @@ extern "C" {
 int hmv_version(void) { return HMV_VERSION; }
 const char* hmv_last_error(void) { return g_err; }
 int hmv_pad(int m) { return pad_of(m); }
+
+int hmv_set_tuning(int key, int64_t value) {
+  if (key < 1 || key >= N_TUNE) return fail(-1, "hmv_set_tuning: unknown key");
+  if (value < kTuneRange[key].lo || value > kTuneRange[key].hi) return fail(-1, "hmv_set_tuning: value out of range");
+  g_tune[key].store(value, std::memory_order_relaxed);
+  return 0;
+}
+int64_t hmv_get_tuning(int key) { return hmv::tuning(key); }
 
 int64_t hmv_yw_workspace_doubles(int m, int p) {
   const int mp = pad_of(m);
@@ -270,7 +302,7 @@ TfFfWs tf_ff_layout(int64_t n, int mp, int p, int F) {
 int64_t norm_lag_items(int mp, int F) {
   const int64_t slots = (mp == 64 || mp == 48) ? 1024 : (mp == 32 ? 2048 : 5120);
   int64_t lag = (6 * slots + F - 1) / (F < 1 ? 1 : F);
-  if (const char* e = getenv("HYPERMVAR_NORM_LAG")) lag = atoll(e);      // tuning experiments only
+  if (const int64_t t = hmv::tuning(HMV_TUNE_NORM_LAG)) lag = t;        // hmv_set_tuning: experiments and tests
   return lag < 8 ? 8 : lag;
 }
 }  // namespace
@@ -314,9 +346,14 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
   a.stamps = g_tf_stamps;
 #endif
   hipStream_t st = S(stream);
-  if (ev_k3_start) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st);
-  int rc = hmv::launch_tf_inv(a, mp, st);
-  if (ev_k3_stop) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st);
+  int rc = 0;
+  if (ev_k3_start) rc = (int)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st);
+  if (rc) return rc;
+  rc = hmv::launch_tf_inv(a, mp, st);
+  if (ev_k3_stop) {
+    const int erc = (int)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st);
+    if (!rc) rc = erc;
+  }
   if (rc) return rc;
   if (n_fused < n_items)
     rc = hmv_ffdtf_norm_f64(a.P + (size_t)n_fused * F * t, a.rowsum + (size_t)n_fused * F * mp, den + (size_t)n_fused * mp,
@@ -444,15 +481,22 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
                              (tiled ? HMV_FLAG_YW_TILED : HMV_FLAG_YW_ONE_LAUNCH);
     const int64_t c0 = (split && tiled && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
     if (c1 > 0) {
-      (void)hipEventRecord(fj->fork, st0);
-      (void)hipStreamWaitEvent(st1, fj->fork, 0);
+      // fork: st1 may start once K1 is done.  Whatever happens on st1 afterwards, st0 joins it again before this call
+      // returns, so that the caller's stream never runs ahead of work this call put on the second stream.
+      int hrc = (int)hipEventRecord(fj->fork, st0);
+      if (!hrc) hrc = (int)hipStreamWaitEvent(st1, fj->fork, 0);
+      if (hrc) { rc = hrc; break; }                      // nothing was put on st1
       rc = hmv_yw_solve_f64(R + (size_t)c0 * (p + 1) * t, c1, m, p, ws + (size_t)c0 * ws_item,
                             ar_c + (size_t)c0 * t * p, V_c + (size_t)c0 * t, nullptr, info_yw + i0 + c0, yw_flags, st1);
-      (void)hipEventRecord(fj->join, st1);
+      hrc = (int)hipEventRecord(fj->join, st1);
+      if (!hrc) hrc = (int)hipStreamWaitEvent(st0, fj->join, 0);
+      if (hrc) {                                         // cannot express the join as an event: join on the host
+        (void)hipStreamSynchronize(st1);
+        if (!rc) rc = hrc;
+      }
       if (rc) break;
     }
     rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, yw_flags, st0);
-    if (c1 > 0) (void)hipStreamWaitEvent(st0, fj->join, 0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
     rc = hmv_tf_ffdtf_f64(ar_c, c, m, p, tw, F, ffdtf + (size_t)i0 * m * m * F, den, nullptr, info_tf + (size_t)i0 * F, pivot_tau,

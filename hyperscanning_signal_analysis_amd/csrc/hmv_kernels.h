@@ -5,6 +5,9 @@
 
 namespace hmv {
 
+// ---- tuning knobs (capi.hip; include/hypermvar.h hmv_set_tuning).  Read by the launchers, never by kernels.
+long long tuning(int key);
+
 // ---- K1 lag covariance ------------------------------------------------------------------------
 struct LagcovArgs {
   const double* x;          // [n_rec][m][ld]  (channel-major, sample-contiguous)

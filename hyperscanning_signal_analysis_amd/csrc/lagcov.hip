@@ -185,8 +185,7 @@ int launch_lagcov(const LagcovArgs& a, int m_pad, hipStream_t st) {
   if (a.n_items == 0) return 0;
   if (a.p > LC_HALO) return -2;
   // every lag's sum runs over the same samples in the same order whatever the grouping: same bits for any LG
-  int lg = 3;
-  if (const char* e = getenv("HYPERMVAR_LAG_GROUP")) lg = atoi(e);      // tuning experiments only
+  const long long lg = tuning(2 /* HMV_TUNE_LAG_GROUP */);
   switch (lg) {
     case 1: return launch_lagcov_lg<1>(a, m_pad, st);
     case 2: return launch_lagcov_lg<2>(a, m_pad, st);

@@ -870,7 +870,7 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
   if (fused) {
     if (!a.P || !a.den || !a.wcount || !a.ready || !a.missed || a.lag < 1) return -3;
     // wcount, ready and missed[0] are one zeroed block (capi.hip lays them out back to back)
-    (void)hipMemsetAsync(a.wcount, 0, sizeof(int) * (2 * (size_t)a.n_items + 1), st);
+    if (const hipError_t e = hipMemsetAsync(a.wcount, 0, sizeof(int) * (2 * (size_t)a.n_items + 1), st)) return (int)e;
   } else {
     a.ff = nullptr;
   }

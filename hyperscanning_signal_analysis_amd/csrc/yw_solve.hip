@@ -487,7 +487,7 @@ template <int NT>
 static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   const int p = a.p;
   const unsigned n = (unsigned)a.n_items;
-  (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
+  if (const hipError_t e = hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st)) return (int)e;
   for (int tb = 0; tb <= p; ++tb) {          // tile column tb: p - tb + 1 tiles per window, the diagonal one included
     const dim3 grid(((n + 7) / 8) * 8 * (unsigned)(p - tb + 1));
     if (a.Vq_logdet && tb == p) hipLaunchKernelGGL((yw_window_kernel<NT, true, 2>), grid, dim3(256), 0, st, a, tb);
@@ -507,7 +507,7 @@ int launch_yw(const YwArgs& a, int m_pad, hipStream_t st) {
   // faster one: 2.0 ms against 2.26 ms for 599 windows (profiles/r02_ab_notes.md).
   const bool one_launch = a.tiled == 0 || (a.tiled < 0 && !(m_pad == 64 && a.n_items >= 128));
   if (one_launch) {
-    (void)hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st);
+    if (const hipError_t e = hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st)) return (int)e;
     const dim3 grid((unsigned)a.n_items), block(256);
     const bool vq = (a.Vq_logdet != nullptr);
     switch (m_pad) {

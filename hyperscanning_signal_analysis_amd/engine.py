@@ -356,8 +356,17 @@ class Engine:
         info_yw = self.empty(n_items, dtype=torch.int32)
         info_tf = self.empty(n_items * F, dtype=torch.int32)
         g_hop, g_first, g_nwin = (int(v) for v in grid) if grid is not None else (0, 0, 0)
-        if grid is not None and (g_nwin < 1 or n_items % g_nwin or g_hop < 1):
-            raise ValueError("grid = (hop, first, n_win) does not match the number of items")
+        if grid is not None:
+            # With a declared grid K1 addresses the windows by (item // n_win, first + (item % n_win) * hop) and never
+            # reads item_rec / item_start: they must say the same thing, or the results belong to other windows (and a
+            # recording index past n_rec would be read out of bounds).  One device comparison per call.
+            if g_nwin < 1 or n_items % g_nwin or g_hop < 1 or n_items // g_nwin > n_rec:
+                raise ValueError("grid = (hop, first, n_win) does not match the number of items / recordings")
+            k = torch.arange(n_items, dtype=torch.int64, device=self.device)
+            same = torch.equal(item_rec, k // g_nwin) and torch.equal(item_start, g_first + (k % g_nwin) * g_hop)
+            if not same:
+                raise ValueError("grid = (hop, first, n_win) contradicts item_rec / item_start "
+                                 "(items must be recording-major, window-minor on the declared grid)")
         with torch.cuda.device(self.device):
             rc = self.lib.hmv_sliding_ffdtf_f64(
                 x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,

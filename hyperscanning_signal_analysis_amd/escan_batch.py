@@ -35,7 +35,7 @@ import numpy as np
 from . import distributed as hdist
 from .eeg_io import filter_eeg
 from .engine import default_engine
-from .sliding import regular_grid, window_items, window_positions
+from .sliding import hop_positions, regular_grid, window_items
 
 __all__ = ["discover_dyads", "decode_events", "segment_block", "run", "xarray_reader"]
 
@@ -163,8 +163,8 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                     if T < W:
                         say(f"[SKIP] {dyad} {task}/{name}: {T} samples < one window ({W})")
                         continue
-                    n_win = (T - W) // hop + 1
-                    pos, W = window_positions(T, n_win, W)
+                    pos = hop_positions(T, W, hop)       # fixed hop; the tail shorter than one hop is dropped
+                    n_win = len(pos)
                     f = np.asarray(freqs if freqs is not None else np.arange(0.5, min(fs / 2.0, 128.0) + 1e-9, 0.5))
                     xd = eng.to_device(block[None])
                     rec_i, st_i = window_items(1, pos, eng.device)

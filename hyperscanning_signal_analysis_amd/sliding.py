@@ -12,7 +12,8 @@ import torch
 
 from .engine import Engine, default_engine
 
-__all__ = ["window_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf_device", "window_items", "regular_grid"]
+__all__ = ["window_positions", "hop_positions", "create_windows", "sliding_ffdtf", "sliding_ffdtf_device", "window_items",
+           "regular_grid"]
 
 
 def window_positions(T: int, n_windows: int = 3, window_size=None):
@@ -44,6 +45,18 @@ def window_positions(T: int, n_windows: int = 3, window_size=None):
         )
     starts = np.linspace(0, last_start, n_windows, dtype=int) if n_windows > 1 else np.zeros(1, dtype=int)
     return starts, int(window_size)
+
+
+def hop_positions(T: int, window_size: int, hop: int):
+    """Starts 0, hop, 2 hop, ... of every whole window of `window_size` samples inside T samples (the tail shorter than
+    one hop is dropped).  This is the fixed-overlap grid of BASELINE config 2 / 5 ("2 s windows, 50 % overlap"); unlike
+    `window_positions` it does not stretch the last window to the end of the recording, so it never refuses a length."""
+    T, window_size, hop = int(T), int(window_size), int(hop)
+    if window_size < 1 or hop < 1:
+        raise ValueError("window_size and hop must be positive")
+    if T < window_size:
+        return np.zeros(0, dtype=int)
+    return np.arange((T - window_size) // hop + 1, dtype=int) * hop
 
 
 def create_windows(signals, n_windows=3, window_size=None):

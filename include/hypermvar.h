@@ -35,6 +35,21 @@ int hmv_version(void);
 const char* hmv_last_error(void);
 /* Padded channel count used by the MP-layout buffers, or -1 if m is unsupported (m < 1 or m > 64). */
 int hmv_pad(int m);
+/* Tuning knobs (process-wide; never needed for correct results -- every setting gives the same numbers up to the
+ * documented bit-identity classes).  They replace the environment variables that earlier builds read inside the
+ * launch path: the environment is looked at ONCE, when the library is loaded (HYPERMVAR_NORM_LAG,
+ * HYPERMVAR_LAG_GROUP, HYPERMVAR_K3_FORM, HYPERMVAR_YW_FORM), and hmv_set_tuning overrides it afterwards.
+ *   HMV_TUNE_NORM_LAG   windows between a K3 workgroup and the window whose rows it normalises (0 = built-in rule, >= 8)
+ *   HMV_TUNE_LAG_GROUP  lags per K1 workgroup (1..3; 0 = default 3)
+ *   HMV_TUNE_K3_FORM    0 = default, 1 = compiler-scheduled K3 body, 2 = hand-scheduled 64-channel K3 body
+ *   HMV_TUNE_YW_FORM    0 = default, 1 = block LDL^T of the augmented matrix, 2 = block Levinson-Whittle recursion
+ * Returns 0, or -1 for an unknown key / value out of range.  hmv_get_tuning returns the value in force (-1: unknown key). */
+#define HMV_TUNE_NORM_LAG 1
+#define HMV_TUNE_LAG_GROUP 2
+#define HMV_TUNE_K3_FORM 3
+#define HMV_TUNE_YW_FORM 4
+int hmv_set_tuning(int key, int64_t value);
+int64_t hmv_get_tuning(int key);
 /* Number of doubles of K2 scratch per item. */
 int64_t hmv_yw_workspace_doubles(int m, int p);
 

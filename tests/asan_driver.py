@@ -68,4 +68,8 @@ assert all(rc < 0 for rc in bad), bad
 assert lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == 0
 assert lib.hmv_tf_ffdtf_f64(D, 0, 4, 2, D, 4, D, D, 0, D, 1.0, D, 0, 0, 0, 0, 0) == 0        # empty batches: nothing to do
 assert len(lib.hmv_last_error()) > 0
+# tuning knobs: range-checked, readable back, process-wide
+assert lib.hmv_set_tuning(1, 16) == 0 and lib.hmv_get_tuning(1) == 16 and lib.hmv_set_tuning(1, 0) == 0
+assert lib.hmv_set_tuning(0, 1) < 0 and lib.hmv_set_tuning(99, 1) < 0 and lib.hmv_set_tuning(2, 7) < 0 and lib.hmv_set_tuning(3, -1) < 0
+assert lib.hmv_get_tuning(99) == -1 and lib.hmv_get_tuning(2) == 0
 print(f"asan driver ok: {n + len(bad)} calls")

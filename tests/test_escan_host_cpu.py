@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from hyperscanning_signal_analysis_amd import escan_batch as EB
-from hyperscanning_signal_analysis_amd.sliding import regular_grid, window_positions
+from hyperscanning_signal_analysis_amd.sliding import hop_positions, regular_grid, window_positions
 from tests.test_gpu_escan_batch import CHANS, FS, _reader, _write
 
 
@@ -67,3 +67,21 @@ def test_regular_grid_detection():
     assert regular_grid([0, 500, 1001], 1000, 8) is None and regular_grid([0], 1000, 8) is None
     pos2, w2 = window_positions(480, 5, 160)                                               # linspace(.., dtype=int) grid of G4
     assert regular_grid(pos2, w2, 5) == (80, 0, 5)
+
+
+@pytest.mark.parametrize("T,W,hop,want", [(1200, 1000, 500, [0]), (1400, 1000, 500, [0]), (1500, 1000, 500, [0, 500]),
+                                          (2300, 1000, 1000, [0, 1000]), (5001, 1000, 500, list(range(0, 4001, 500))),
+                                          (999, 1000, 500, []), (1000, 1000, 500, [0])])
+def test_fixed_hop_grid_never_refuses_a_segment_length(T, W, hop, want):
+    """Segments are cut with an inclusive time mask (dur * fs + 1 samples) and are almost never a whole number of hops:
+    the fixed-hop grid drops the tail and stays regular (so K1 can share the overlap), where the reference's
+    `_create_windows` arithmetic (`window_positions`) would refuse W < T < 1.5 W or any T that is not a multiple of W
+    at zero overlap -- the failure that used to discard a whole dyad."""
+    pos = hop_positions(T, W, hop)
+    assert pos.tolist() == want
+    assert all(s + W <= T for s in pos)
+    if len(pos) >= 2 and W % hop == 0 and 2 <= W // hop <= 8:
+        assert regular_grid(pos, W, 8) == (hop, 0, len(pos))
+    if T in (1200, 1400, 2300):
+        with pytest.raises(ValueError):
+            window_positions(T, (T - W) // hop + 1, W)

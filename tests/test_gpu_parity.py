@@ -402,8 +402,10 @@ def test_two_stream_overlap_is_bit_identical():
 def test_normalisation_inside_k3_is_bit_identical_to_separate_pass(m, n, p, F, nw):
     """ffDTF normalised inside K3 by the workgroup that completes a window (device-scope arrival counter,
     release / acquire) == |H|^2 written out and normalised by the separate K4 pass, bit for bit, for every
-    window -- the ones inside the batch (fused) and the last few (always left to K4).  (A grid that is not a
-    multiple of 16 frequencies, the last case, is normalised by K4 throughout.)"""
+    window -- the ones inside the batch (fused) and the last few (always left to K4).  With the built-in lag rule
+    (6 x resident windows) only the 64- and 48-channel cases with enough windows actually fuse here (cases 1, 5, 6);
+    the others, and a grid that is not a multiple of 16 frequencies (the last case), are normalised by K4 throughout --
+    `test_normalisation_inside_k3_with_a_short_lag` below forces the fused path for the small shapes."""
     from hyperscanning_signal_analysis_amd import _lib
     from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
     eng = default_engine()
@@ -422,6 +424,35 @@ def test_normalisation_inside_k3_is_bit_identical_to_separate_pass(m, n, p, F, n
     assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
     k = nw // 2
     assert_parity(fused[k].cpu().numpy(), O.full_freq_dtf(x[:, pos[k]:pos[k] + w], freqs, 500.0, p), 1e-8)
+
+
+@pytest.mark.parametrize("m,n,p,F,nw,lag", [(4, 160, 5, 32, 300, 8), (19, 400, 3, 32, 150, 8), (33, 300, 2, 16, 200, 8),
+                                              (64, 1000, 8, 32, 60, 8), (64, 1000, 8, 256, 24, 9), (48, 600, 4, 16, 200, 8)])
+def test_normalisation_inside_k3_with_a_short_lag(m, n, p, F, nw, lag):
+    """The built-in lag rule (6 x the windows the chip holds) leaves small matrices and short grids entirely to K4, so the
+    16- and 32-channel instantiations of the publish / denominator / row-worker path and `norm_missed_kernel` would never
+    run under the other tests.  With the lag forced to 8 (hmv_set_tuning) every shape fuses all but its last 8 windows, and
+    rows regularly come up before their window is complete (they go through the missed-row list): still the same bits
+    as the separate K4 pass, for every window, twice in a row (the workspace is reused)."""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(13, m=m, p=min(p, 4), T=T, burn=300)
+    freqs = np.linspace(0.5, 120.0, F)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    plain = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, flags=_lib.FLAG_UNFUSED_NORM)
+    assert eng.lib.hmv_set_tuning(_lib.TUNE_NORM_LAG, lag) == 0 and eng.lib.hmv_get_tuning(_lib.TUNE_NORM_LAG) == lag
+    try:
+        fused = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)
+        again = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)
+        torch.cuda.synchronize()
+    finally:
+        assert eng.lib.hmv_set_tuning(_lib.TUNE_NORM_LAG, 0) == 0
+    assert torch.equal(fused, plain) and torch.equal(again, plain)
+    assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
 
 
 @pytest.mark.parametrize("m,n,p", [(64, 1000, 8), (64, 700, 3), (50, 900, 5), (33, 500, 2), (19, 400, 6), (16, 300, 1),
