@@ -229,6 +229,179 @@ __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- outputs of one inverted matrix
+// Shared by the compiler-scheduled body (tf_inv_kernel) and the hand-scheduled 64-channel body (tf_inv64_asm_kernel):
+// H / |H|^2 / row sums, the write-through publish and the in-kernel ffDTF normalisation.  `smem` is the inversion's
+// LDS block (free after the last barrier of the inversion), `rsum` NT * MP doubles inside it that the publish tile does
+// not cover, `s_orig` the column permutation left by the row interchanges, `s_flag` one int of LDS.
+template <int NT, bool GEN>
+__device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, const int f, const long long gw, const int w,
+                                           const int wv, double (&re)[NT][4], double (&im)[NT][4], double2* smem,
+                                           double* rsum, const int* s_orig, int* s_flag, const double* s_det
+#ifdef HMV_STAMP
+                                           , unsigned long long (&tsum)[8], unsigned long long& tlast
+#endif
+) {
+  constexpr int MP = 16 * NT, NG = NT;
+  using L = TfLds<NT>;
+  constexpr int NR = L::NRING;
+  int& s_info = *s_flag;
+  // ---------------------------------------------------------------- outputs
+  // Lane coordinates are re-derived from an opaque lane id: reusing the prologue's row indices would keep
+  // them alive across the whole sweep (they were spilled to scratch once: 2.5 GB per launch).
+  int lo;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+  const int rowo = 4 * ((lo >> 2) & 3) + (lo >> 4), jo = lo & 3;
+  int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
+#pragma unroll
+  for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[4 * (Jl * NT + w) + jo];
+  if (w == 0 && lo == 0) {
+    a.info[gw] = s_info;
+    if constexpr (GEN) {
+      if (a.detph) {
+        a.detph[2 * gw] = s_det[0];
+        a.detph[2 * gw + 1] = s_det[1];
+      }
+    }
+  }
+
+  if (a.H) {
+    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)rowo * MP;
+#pragma unroll
+    for (int Ig = 0; Ig < NG; ++Ig)
+#pragma unroll
+      for (int Jl = 0; Jl < 4; ++Jl) Ho[(size_t)(16 * Ig) * MP + oc[Jl]] = make_double2(re[Ig][Jl], im[Ig][Jl]);
+  }
+  if (a.P) {
+    double* rs = rsum + w * MP + rowo;
+    const bool publish = !GEN && a.ff != nullptr && item < a.fuse_items;     // workgroup-uniform
+    if (!publish) {
+      double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
+#pragma unroll
+      for (int Ig = 0; Ig < NG; ++Ig) {
+        double acc = 0.0;
+#pragma unroll
+        for (int Jl = 0; Jl < 4; ++Jl) {
+          const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
+          Po[(size_t)(16 * Ig) * MP + oc[Jl]] = v;
+          acc += v;
+        }
+        acc += dpp_f64<0xB1>(acc);      // sum over the four lanes j of the quad (fixed order)
+        acc += dpp_f64<0x4E>(acc);
+        if (jo == 0) rs[16 * Ig] = acc;
+      }
+      __syncthreads();
+      if (w == 0 && lo < MP) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // fixed order: bit-reproducible
+        a.rowsum[(size_t)gw * MP + lo] = t;
+      }
+    } else {
+      // This matrix will be read by ANOTHER workgroup inside this launch (the one that completes the window),
+      // so it is published write-through: |H|^2 goes through LDS (16*G rows at a time) and leaves as whole rows,
+      // 16 bytes per lane, with device-scope (sc1) stores that bypass the non-coherent L2 -- no L2 write-back
+      // (a per-workgroup release fence walks the whole 4 MB L2 and serialises: 36 ms instead of 8.4, measured).
+      constexpr int G = (NT == 3) ? 1 : (NT == 4 ? 2 : NT), TS = MP + 2, C2 = MP / 2, CNT = 16 * G * C2;
+      static_assert(16 * G * TS <= 2 * (L::PBUF + NR * L::NBUF + L::SROW + L::SWAPB), "publish tile overlaps the row sums");
+      double* tile = reinterpret_cast<double*>(smem);
+      // published layout Pp[item][row][f][col]: row-major over frequency (see normalise_row)
+      double* Pg = a.P + (size_t)item * MP * a.F * MP + (size_t)f * MP;
+      static_for<NG / G>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pc)::value;
+        if (pass > 0) __syncthreads();            // the previous pass has been read out
+        static_for<G>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value, Ig = pass * G + g;
+          double acc = 0.0;
+#pragma unroll
+          for (int Jl = 0; Jl < 4; ++Jl) {
+            const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
+            tile[(16 * g + rowo) * TS + oc[Jl]] = v;
+            acc += v;
+          }
+          acc += dpp_f64<0xB1>(acc);
+          acc += dpp_f64<0x4E>(acc);
+          if (jo == 0) rs[16 * Ig] = acc;
+        });
+        __syncthreads();
+#pragma unroll
+        for (int idx = threadIdx.x; idx < CNT; idx += 64 * NT) {
+          const int row = idx / C2, c2 = idx - row * C2;
+          const f64x2 v = *reinterpret_cast<const f64x2*>(tile + row * TS + 2 * c2);
+          store_sc1_b128(Pg + (size_t)(16 * G * pass + row) * a.F * MP + 2 * c2, v);
+        }
+      });
+      if (w == 0 && lo < MP) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // same order as above
+        store_sc1_b64(a.rowsum + (size_t)gw * MP + lo, t);
+      }
+    }
+  }
+#ifdef HMV_STAMP
+  HMV_T(6);
+  if (a.stamps && lo == 0) {
+    for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
+  }
+#endif
+
+  // ---------------------------------------------------------------- fused normalisation (ffDTF)
+  // This workgroup's |H|^2 and row sums were stored write-through (sc1).  Every storing wave drains its stores,
+  // workgroup barrier, then ONE lane counts the matrix on its window (device-scope atomic).  The workgroup whose
+  // count completes the window (agent-scope acquire: its CU's L1 is invalidated) adds up the denominators and
+  // raises ready[window].  Nobody waits for anybody.
+  if constexpr (!GEN) {
+    if (a.ff != nullptr) {                                   // kernel-uniform
+      static_assert(NormLds<NT>::DOUBLES <= 2 * L::TOTAL, "normaliser tiles do not fit the inversion's LDS block");
+      double* nlds = reinterpret_cast<double*>(smem);
+      if (item < a.fuse_items) {                             // workgroup-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const int old = __hip_atomic_fetch_add(a.wcount + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int last = (old == a.F - 1) ? 1 : 0;
+          if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          s_info = last;
+        }
+        __syncthreads();
+        if (s_info != 0) {
+          window_denominators<NT>(a, item, nlds);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (threadIdx.x == 0) __hip_atomic_store(a.ready + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // Rows f, f + F, ... of window item - lag are this workgroup's to normalise.
+      const int wl = item - a.lag;
+      if (wl >= 0 && wl < a.fuse_items && f < a.m) {         // workgroup-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          // No acquire fence here (it costs ~7 us with four workgroups on the CU, 38 000 times per launch): the
+          // flag and the denominator are read with device-scope (sc1) loads, and the |H|^2 rows with non-temporal
+          // loads that bypass this CU's L1 -- every one of those lines was written write-through before ready[wl]
+          // was raised and is read exactly once in the whole launch, so no cache can hold an older copy of it.
+          const int rdy = __hip_atomic_load(a.ready + wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!rdy) {
+            for (int i = f; i < a.m; i += a.F) {
+              const int pos = __hip_atomic_fetch_add(a.missed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              a.missed[1 + pos] = wl * MP + i;
+            }
+          }
+          s_info = rdy;
+        }
+        __syncthreads();
+        if (s_info != 0) {
+          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds);
+        }
+      }
+    }
+  }
+}
+
 // GEN = false: A(f) from the AR coefficients (the hot path).  GEN = true: the same inversion of arbitrary
 // complex matrices Zin[item][f][MP][MP] (partial coherence of a spectral matrix, mtmvar.py:287-338), which
 // also returns the unit-modulus phase of the determinant (product of the pivots, sign of the interchanges).
@@ -656,160 +829,68 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
   });
 
   HMV_T(5);
-  // ---------------------------------------------------------------- outputs
-  // Lane coordinates are re-derived from an opaque lane id: reusing the prologue's row indices would keep
-  // them alive across the whole sweep (they were spilled to scratch once: 2.5 GB per launch).
-  int lo;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
-  const int rowo = 4 * ((lo >> 2) & 3) + (lo >> 4), jo = lo & 3;
-  int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
-#pragma unroll
-  for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[4 * (Jl * NT + w) + jo];
-  if (w == 0 && lo == 0) {
-    a.info[gw] = s_info;
-    if constexpr (GEN) {
-      if (a.detph) {
-        a.detph[2 * gw] = s_det[0];
-        a.detph[2 * gw + 1] = s_det[1];
-      }
-    }
-  }
-
-  if (a.H) {
-    double2* Ho = reinterpret_cast<double2*>(a.H) + (size_t)gw * MP * MP + (size_t)rowo * MP;
-#pragma unroll
-    for (int Ig = 0; Ig < NG; ++Ig)
-#pragma unroll
-      for (int Jl = 0; Jl < 4; ++Jl) Ho[(size_t)(16 * Ig) * MP + oc[Jl]] = make_double2(re[Ig][Jl], im[Ig][Jl]);
-  }
-  if (a.P) {
-    double* rs = rsum + w * MP + rowo;
-    const bool publish = !GEN && a.ff != nullptr && item < a.fuse_items;     // workgroup-uniform
-    if (!publish) {
-      double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
-#pragma unroll
-      for (int Ig = 0; Ig < NG; ++Ig) {
-        double acc = 0.0;
-#pragma unroll
-        for (int Jl = 0; Jl < 4; ++Jl) {
-          const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
-          Po[(size_t)(16 * Ig) * MP + oc[Jl]] = v;
-          acc += v;
-        }
-        acc += dpp_f64<0xB1>(acc);      // sum over the four lanes j of the quad (fixed order)
-        acc += dpp_f64<0x4E>(acc);
-        if (jo == 0) rs[16 * Ig] = acc;
-      }
-      __syncthreads();
-      if (w == 0 && lo < MP) {
-        double t = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // fixed order: bit-reproducible
-        a.rowsum[(size_t)gw * MP + lo] = t;
-      }
-    } else {
-      // This matrix will be read by ANOTHER workgroup inside this launch (the one that completes the window),
-      // so it is published write-through: |H|^2 goes through LDS (16*G rows at a time) and leaves as whole rows,
-      // 16 bytes per lane, with device-scope (sc1) stores that bypass the non-coherent L2 -- no L2 write-back
-      // (a per-workgroup release fence walks the whole 4 MB L2 and serialises: 36 ms instead of 8.4, measured).
-      constexpr int G = (NT == 3) ? 1 : (NT == 4 ? 2 : NT), TS = MP + 2, C2 = MP / 2, CNT = 16 * G * C2;
-      static_assert(16 * G * TS <= 2 * (L::PBUF + NR * L::NBUF + L::SROW + L::SWAPB), "publish tile overlaps the row sums");
-      double* tile = reinterpret_cast<double*>(smem);
-      // published layout Pp[item][row][f][col]: row-major over frequency (see normalise_row)
-      double* Pg = a.P + (size_t)item * MP * a.F * MP + (size_t)f * MP;
-      static_for<NG / G>([&](auto pc) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pc)::value;
-        if (pass > 0) __syncthreads();            // the previous pass has been read out
-        static_for<G>([&](auto gc) __attribute__((always_inline)) {
-          constexpr int g = decltype(gc)::value, Ig = pass * G + g;
-          double acc = 0.0;
-#pragma unroll
-          for (int Jl = 0; Jl < 4; ++Jl) {
-            const double v = re[Ig][Jl] * re[Ig][Jl] + im[Ig][Jl] * im[Ig][Jl];
-            tile[(16 * g + rowo) * TS + oc[Jl]] = v;
-            acc += v;
-          }
-          acc += dpp_f64<0xB1>(acc);
-          acc += dpp_f64<0x4E>(acc);
-          if (jo == 0) rs[16 * Ig] = acc;
-        });
-        __syncthreads();
-#pragma unroll
-        for (int idx = threadIdx.x; idx < CNT; idx += 64 * NT) {
-          const int row = idx / C2, c2 = idx - row * C2;
-          const f64x2 v = *reinterpret_cast<const f64x2*>(tile + row * TS + 2 * c2);
-          store_sc1_b128(Pg + (size_t)(16 * G * pass + row) * a.F * MP + 2 * c2, v);
-        }
-      });
-      if (w == 0 && lo < MP) {
-        double t = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < NT; ++ww) t += rsum[ww * MP + lo];   // same order as above
-        store_sc1_b64(a.rowsum + (size_t)gw * MP + lo, t);
-      }
-    }
-  }
+  tf_outputs<NT, GEN>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, &s_info, s_det
 #ifdef HMV_STAMP
-  HMV_T(6);
-  if (a.stamps && lo == 0) {
-    for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
-  }
+                      , tsum, tlast
 #endif
+  );
+}
 
-  // ---------------------------------------------------------------- fused normalisation (ffDTF)
-  // This workgroup's |H|^2 and row sums were stored write-through (sc1).  Every storing wave drains its stores,
-  // workgroup barrier, then ONE lane counts the matrix on its window (device-scope atomic).  The workgroup whose
-  // count completes the window (agent-scope acquire: its CU's L1 is invalidated) adds up the denominators and
-  // raises ready[window].  Nobody waits for anybody.
-  if constexpr (!GEN) {
-    if (a.ff != nullptr) {                                   // kernel-uniform
-      static_assert(NormLds<NT>::DOUBLES <= 2 * L::TOTAL, "normaliser tiles do not fit the inversion's LDS block");
-      double* nlds = reinterpret_cast<double*>(smem);
-      if (item < a.fuse_items) {                             // workgroup-uniform
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          const int old = __hip_atomic_fetch_add(a.wcount + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int last = (old == a.F - 1) ? 1 : 0;
-          if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          s_info = last;
-        }
-        __syncthreads();
-        if (s_info != 0) {
-          window_denominators<NT>(a, item, nlds);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (threadIdx.x == 0) __hip_atomic_store(a.ready + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      // Rows f, f + F, ... of window item - lag are this workgroup's to normalise.
-      const int wl = item - a.lag;
-      if (wl >= 0 && wl < a.fuse_items && f < a.m) {         // workgroup-uniform
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          // No acquire fence here (it costs ~7 us with four workgroups on the CU, 38 000 times per launch): the
-          // flag and the denominator are read with device-scope (sc1) loads, and the |H|^2 rows with non-temporal
-          // loads that bypass this CU's L1 -- every one of those lines was written write-through before ready[wl]
-          // was raised and is read exactly once in the whole launch, so no cache can hold an older copy of it.
-          const int rdy = __hip_atomic_load(a.ready + wl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!rdy) {
-            for (int i = f; i < a.m; i += a.F) {
-              const int pos = __hip_atomic_fetch_add(a.missed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              a.missed[1 + pos] = wl * MP + i;
-            }
-          }
-          s_info = rdy;
-        }
-        __syncthreads();
-        if (s_info != 0) {
-          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds);
-        }
-      }
-    }
+// ---------------------------------------------------------------- hand-scheduled 64-channel body
+// Same arithmetic as tf_inv_kernel<4, false> (A(f) build and blocked Gauss-Jordan inversion, operation for operation,
+// hence the same bits: tests/test_gpu_parity.py), as ONE asm statement generated by csrc/gen/k3gen.py with every VGPR
+// placed by hand: 96 registers instead of 128, i.e. five workgroups per CU instead of four.  K3 is bound by the latency
+// of the per-step chain (panel-block update -> LDS hand-over -> panel factorisation -> barrier), which only more
+// resident matrices cover; the compiler needs 128 registers for the body and spills ~1 700 at 96.
+// The stream is executed on a CPU emulator against NumPy, and its wait states / wait counts are checked there
+// (tests/test_k3_asm_cpu.py), because hipcc does neither inside an asm statement.
+#include "tf_inv64_body.inc"
+#ifndef HMV_K3A_WGS
+#define HMV_K3A_WGS 5
+#endif
+static_assert(K3A_PBUF == 0 && K3A_NBUF == 16 * TfLds<4>::PBUF && K3A_RSUM == 16 * (TfLds<4>::TOTAL - TfLds<4>::RSUM),
+              "LDS map of the generated body and of the epilogue disagree");
+
+__global__ void __launch_bounds__(256, HMV_K3A_WGS) tf_inv64_asm_kernel(TfArgs a) {
+  constexpr int NT = 4, MP = 64;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[K3A_LDS_TOTAL];
+  int* s_orig = reinterpret_cast<int*>(lds + K3A_SORIG);
+  int* s_flag = reinterpret_cast<int*>(lds + K3A_SINFO);
+  const int wv = uni(threadIdx.x >> 6);
+  const int w = (wv + (int)((blockIdx.x * 2654435761u) >> 20)) % NT;      // same rotation as tf_inv_kernel
+  const int item = uni((int)(blockIdx.x / (unsigned)a.F));
+  const int f = uni((int)(blockIdx.x - (unsigned)item * (unsigned)a.F));
+  const long long gw = (long long)item * a.F + f;
+  if (w == 0) {
+    const int l = lane_id();
+    s_orig[l] = l;
+    if (l == 0) *s_flag = 0;
   }
+  const int p = a.p, P2 = (p + 1) >> 1;
+  const double* arx = a.arx + ((size_t)item * NT + w) * (size_t)(16 * 64 * 2) * P2;
+  const double* tw = a.tw + (size_t)f * p * 2;
+  const double tau = a.tau;
+  const unsigned ldsbase = (unsigned)(uintptr_t)lds;
+  double acc[32];
+  K3A_BODY(acc, arx, tw, p, w, tau, ldsbase);
+  double re[NT][4], im[NT][4];
+#pragma unroll
+  for (int Ig = 0; Ig < 4; ++Ig)
+#pragma unroll
+    for (int Jl = 0; Jl < 4; ++Jl) {
+      re[Ig][Jl] = acc[2 * (4 * Ig + Jl)];
+      im[Ig][Jl] = acc[2 * (4 * Ig + Jl) + 1];
+    }
+  double2* smem = reinterpret_cast<double2*>(lds);
+  double* rsum = reinterpret_cast<double*>(lds + K3A_RSUM);
+#ifdef HMV_STAMP
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+  tf_outputs<NT, false>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, s_flag, nullptr
+#ifdef HMV_STAMP
+                        , tsum, tlast
+#endif
+  );
 }
 
 // ---------------------------------------------------------------- coefficient packing
@@ -894,7 +975,11 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
       break;
     case 64:
       hipLaunchKernelGGL(ar_pack_kernel<4>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
-      hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), 0, st, a);
+      // the hand-scheduled body has no A(f) output (asked for by the staged API only)
+      if (tuning(3 /* HMV_TUNE_K3_FORM */) != 1 && a.A == nullptr)
+        hipLaunchKernelGGL(tf_inv64_asm_kernel, grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), 0, st, a);
       break;
     default: return -1;
   }

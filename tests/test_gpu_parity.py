@@ -455,6 +455,69 @@ def test_normalisation_inside_k3_with_a_short_lag(m, n, p, F, nw, lag):
     assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
 
 
+@pytest.mark.parametrize("m,p,F,scale", [(64, 8, 32, 0.05), (64, 2, 16, 3.0), (50, 5, 16, 2.0), (64, 16, 16, 0.3),
+                                          (64, 1, 16, 5.0), (57, 3, 48, 1.0), (64, 7, 16, 0.5)])
+def test_hand_scheduled_k3_body_equals_compiler_body(m, p, F, scale):
+    """The 64-channel body of K3 with hand-allocated registers (csrc/gen/k3gen.py, five workgroups per CU) against the
+    compiler-scheduled body (four per CU): H, |H|^2, the row sums and info are the same BITS -- same A(f) build (every
+    order: full chunks of eight lags, single lag pairs, the zero padding lag of an odd order), same pivot choices, same
+    summation order.  Large coefficients (scale >= 1) make nearly every pivot column interchange rows, which takes the
+    stream through its search path, the displaced-row path and the other waves' row swaps; and both agree with NumPy."""
+    from hyperscanning_signal_analysis_amd import _lib
+    eng = default_engine()
+    mp = eng.pad(m)
+    assert mp == 64
+    rng = np.random.default_rng(100 * p + F)
+    items = 5
+    ar = np.zeros((items, mp, mp, p))
+    ar[:, :m, :m, :] = scale * rng.standard_normal((items, m, m, p)) / np.sqrt(m)
+    ar[:, np.arange(m), np.arange(m), 0] += 0.4
+    freqs = np.linspace(1.0, 200.0, F)
+    tw = eng.twiddles(freqs, 500.0, p)
+    ard = eng.to_device(ar)
+    outs = {}
+    try:
+        for form in (1, 2):
+            assert eng.lib.hmv_set_tuning(_lib.TUNE_K3_FORM, form) == 0
+            outs[form] = eng.transfer(ard, m, tw, want_P=True, want_H=True)
+            torch.cuda.synchronize()
+    finally:
+        assert eng.lib.hmv_set_tuning(_lib.TUNE_K3_FORM, 0) == 0
+    a, b = outs[1], outs[2]
+    assert not bool(a["info"].any()) and not bool(b["info"].any())
+    for k in ("H", "P", "rowsum", "info"):
+        assert torch.equal(a[k], b[k]), k
+    H = torch.view_as_complex(b["H"])[2, :, :m, :m].cpu().numpy()
+    z = np.exp(-(np.arange(p) + 1) * 2 * np.pi * 1j * freqs[:, None] / 500.0)          # (F, p)
+    A = np.eye(m)[None] - np.einsum("ijk,fk->fij", ar[2, :m, :m, :], z)
+    want = np.linalg.inv(A)
+    assert np.abs(H - want).max() / np.abs(want).max() < 1e-9
+    if scale >= 1.0:                    # the interchange paths really ran: the inverse of a non-dominant matrix
+        assert (np.abs(A[0]).argmax(axis=0) != np.arange(m)).any()
+
+
+def test_hand_scheduled_k3_body_in_the_fused_path():
+    """the whole sliding-window call (ffDTF normalised inside K3) with either body: same bits"""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    x = synthetic_var_dyad(17, m=64, p=4, T=16_000, burn=300)
+    freqs = northstar_freqs()
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(16_000, 31, 1000)
+    rec, st = window_items(1, pos, eng.device)
+    outs = {}
+    try:
+        for form in (1, 2):
+            assert eng.lib.hmv_set_tuning(_lib.TUNE_K3_FORM, form) == 0
+            outs[form] = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0)
+            torch.cuda.synchronize()
+    finally:
+        assert eng.lib.hmv_set_tuning(_lib.TUNE_K3_FORM, 0) == 0
+    assert torch.equal(outs[1], outs[2])
+    assert float((outs[2].sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
+
+
 @pytest.mark.parametrize("m,n,p", [(64, 1000, 8), (64, 700, 3), (50, 900, 5), (33, 500, 2), (19, 400, 6), (16, 300, 1),
                                    (5, 200, 9)])
 def test_yule_walker_one_launch_equals_tiled_launch_chain(m, n, p):
