@@ -67,6 +67,7 @@ TUNE_NORM_LAG = 1
 TUNE_LAG_GROUP = 2
 TUNE_K3_FORM = 3
 TUNE_YW_FORM = 4
+TUNE_K3_LDS_PAD = 5
 
 
 _lib = None

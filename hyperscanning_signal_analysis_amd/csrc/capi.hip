@@ -19,9 +19,9 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
 
 // Tuning knobs: the environment is parsed once, at load time, with range checks; hmv_set_tuning overrides.
-constexpr int N_TUNE = 5;
+constexpr int N_TUNE = 6;
 struct TuneRange { long long lo, hi; };
-constexpr TuneRange kTuneRange[N_TUNE] = {{0, 0}, {0, 1 << 20}, {0, 3}, {0, 2}, {0, 2}};
+constexpr TuneRange kTuneRange[N_TUNE] = {{0, 0}, {0, 1 << 20}, {0, 3}, {0, 2}, {0, 2}, {0, 140000}};
 long long env_knob(const char* name, int key) {
   const char* e = getenv(name);
   if (!e || !*e) return 0;
@@ -35,7 +35,8 @@ long long env_knob(const char* name, int key) {
   return v;
 }
 std::atomic<long long> g_tune[N_TUNE] = {{0}, {env_knob("HYPERMVAR_NORM_LAG", 1)}, {env_knob("HYPERMVAR_LAG_GROUP", 2)},
-                                         {env_knob("HYPERMVAR_K3_FORM", 3)}, {env_knob("HYPERMVAR_YW_FORM", 4)}};
+                                         {env_knob("HYPERMVAR_K3_FORM", 3)}, {env_knob("HYPERMVAR_YW_FORM", 4)},
+                                         {env_knob("HYPERMVAR_K3_LDS_PAD", 5)}};
 }  // namespace
 
 namespace hmv {

@@ -588,6 +588,10 @@ class Wave:
         assert d.kind == "vcc"
         self._vcmp_write(d, self.rdf64(x) > self.rdf64(y))
 
+    def op_v_cmp_lt_f64_e32(self, it, d, x, y):
+        assert d.kind == "vcc"
+        self._vcmp_write(d, self.rdf64(x) < self.rdf64(y))
+
     def op_v_cmp_gt_f64_e64(self, it, d, x, y):
         self._vcmp_write(d, self.rdf64(x) > self.rdf64(y))
 

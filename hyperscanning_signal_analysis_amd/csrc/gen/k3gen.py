@@ -75,6 +75,10 @@ sRS = [S(68 + k) for k in range(4)]
 sRSTAR, sKMAX, sM1 = S(72), S(73), S(74, 2)
 sIGS, sT0, sT1, sT2 = S(76), S(77), S(78), S(79)
 sOKC = [S(80 + 2 * k, 2) for k in range(4)]
+# `rlpiv` variant: the pivot row's other three columns as six SGPR pairs (re, im per column); the per-column |pivot|^2 > 0
+# masks are not kept then (a branch records the first bad column in sBAD instead)
+PVS = [S(80, 2), S(82, 2), S(84, 2), S(86, 2), S(44, 2), S(46, 2)]
+sBAD = S(66)
 # A(f) phase only (the twiddles occupy s[48:79] then): running pointers and counters
 sPTR, sTWP, sCH, sA1, sA2, sSTRIDE = S(80, 2), S(82, 2), S(84), S(85), S(86), S(88)
 TW0 = 48                         # twiddles of a chunk of 8 lags: s[48:79]
@@ -82,7 +86,30 @@ CLOBBER_S = (36, 89)             # [lo, hi)
 
 
 class Gen:
-    def __init__(self, for_text: bool, build_af: bool = True, with_slow: bool = True):
+    # stream variants (same arithmetic, except `ldsconst`, which may turn a -0.0 into +0.0 on the pivot row's lane):
+    #   earlyswz  B operands of the first block requested before the interchange flag is known (redone after a swap)
+    #   hoist     address arithmetic of the factorisation placed in LDS-latency shadows instead of the dependent chain
+    #   ldsconst  the pivot row's lane gets its zeroed row and its unit multiplier by LDS reads of constants instead of
+    #             eight exec-masked VALU instructions per pivot column
+    #   rlpiv     the pivot row travels through twelve v_readlane into SGPRs (FMA scalar operands) instead of an LDS
+    #             publish / broadcast round trip per pivot column; excludes ldsconst
+    #   spec      (with rlpiv) the four pivot columns of a panel run without a single branch: "some row beats the
+    #             diagonal" and "pivot not > 0" only set a flag (SALU), tested once per panel; a flagged panel is redone
+    #             from its LDS copy by the careful column code (v_cmp -> s_cbranch -> VALU costs ~42 cycles, twice per
+    #             column, on the workgroup's critical path)
+    #   preaddr   the factorisation's LDS addresses are computed one step ahead, by the wave that will factor next, while
+    #             it waits for the current factorisation (instead of right behind its barrier)
+    # Same-box A/B (profiles/r03_k3_ab_notes.md): none of the variants moves K3 by more than 1 %; rlpiv is the fastest
+    # by that margin and keeps LDS traffic out of the column loop; spec / preaddr / ldsconst measured neutral or slower.
+    DEFAULT_OPTS = ("earlyswz", "hoist", "rlpiv")
+
+    def __init__(self, for_text: bool, build_af: bool = True, with_slow: bool = True, opts=None):
+        self.opts = set(self.DEFAULT_OPTS if opts is None else opts)
+        self.stamps = "stamps" in self.opts        # diagnostic build: s_memtime sums per phase (see stamp())
+        if "rlpiv" in self.opts:
+            self.opts.discard("ldsconst")
+        else:
+            self.opts.discard("spec")
         self.p = Program()
         self.for_text = for_text
         self.build_af = build_af
@@ -94,6 +121,35 @@ class Gen:
         else:                    # the emulator places them in s[2:11]
             self.in_arx, self.in_tw = S(2, 2), S(4, 2)
             self.in_p, self.in_w, self.in_tau, self.in_lds = S(6), S(7), S(8, 2), S(10)
+
+    # ------------------------------------------------------------------ diagnostic stamps
+    # Eight 32-bit sums of s_memtime differences in s[92:99] (s90 = last stamp, s[100:101] scratch); every stamp drains
+    # lgkmcnt (s_memtime returns through it).  Phases: 0 A(f) build | 1 barrier wait | 2 loop, waves that do not factor |
+    # 3 chain wave: barrier -> N and flag read | 4 chain wave: B operands + 16 MFMAs | 5 factorisation: panel through LDS
+    # | 6 factorisation: pivot search, reciprocal, pivot row through LDS | 7 factorisation: elimination, N write
+    def stamp(self, phase):
+        if not self.stamps:
+            return
+        p = self.p
+        p.s_memtime(S(100, 2))
+        p.s_waitcnt("lgkmcnt(0)")
+        p.s_sub_u32(S(101), S(100), S(90))
+        p.s_add_u32(S(92 + phase), S(92 + phase), S(101))
+        p.s_mov_b32(S(90), S(100))
+
+    def stamp_init(self):
+        if not self.stamps:
+            return
+        p = self.p
+        p.s_memtime(S(100, 2))
+        for k in range(4):
+            p.s_mov_b64(S(92 + 2 * k, 2), 0)
+        p.s_waitcnt("lgkmcnt(0)")
+        p.s_mov_b32(S(90), S(100))
+
+    def setprio(self, n):
+        if "noprio" not in self.opts:
+            self.p.s_setprio(n)
 
     # ------------------------------------------------------------------ prologue: constants
     def prologue(self):
@@ -321,6 +377,13 @@ class Gen:
             p.s_cbranch_scc1(L_nxt)
         # ---- other waves: update s of all four blocks
         self.role_body(s, "oth", [0, 1, 2, 3])
+        if "preaddr" in self.opts and s + 2 < NSTEP:
+            # the wave that factors panel s + 2 during step s + 1 is one of these: its addresses, while it would wait
+            L_pa = p.newlabel(f"S{s}_pa")
+            p.s_cmp_lg_u32(sW, (s + 2) % NT)
+            p.s_cbranch_scc1(L_pa)
+            self.factor_addresses()
+            p.label(L_pa)
         p.s_branch(L_end)
         # ---- owner of panel s
         p.label(L_own)
@@ -343,27 +406,40 @@ class Gen:
             p.s_branch(L_end)
             # ---- owner of panel s + 1: its panel block only, then the factorisation
             p.label(L_nxt)
-            p.s_setprio(3)
-            self.role_body(s, "nxt", [Jn])
-            self.factor_panel(s + 1, Jn)
-            p.s_setprio(0)
+            self.setprio(3)
+            pre = "preaddr" in self.opts
+            self.role_body(s, "nxt", [Jn], hook=self.factor_addresses if ("hoist" in self.opts and not pre) else None)
+            self.stamp(4)
+            self.factor_panel(s + 1, Jn, have_addresses="hoist" in self.opts or pre)
+            self.setprio(0)
         p.label(L_end)
         p.s_waitcnt("lgkmcnt(0)")
+        self.stamp(2)
         p.s_barrier()
-        roles = [("own", own)] + ([("nxt", nxt)] if has_next else [])
+        self.stamp(1)
+        roles = [("own", own, [J for J in range(4) if J != Js][0])] + ([("nxt", nxt, Jn)] if has_next else [])
         if self.with_slow:
             self.cold.append(lambda: self.interchange_cold(s, f"S{s}_swap", roles))
         else:
             self.cold.append(lambda: (p.label(f"S{s}_swap"), p.s_endpgm()))
 
-    def role_body(self, s, role, blocks, take=None):
+    def role_body(self, s, role, blocks, take=None, hook=None):
         """load N_s, check the interchange flag, (take the panel), update `blocks`"""
         p = self.p
+        early = "earlyswz" in self.opts and bool(blocks)
         L_slow, L_back = f"S{s}_swap", f"S{s}_{role}_swapped"
         self.load_n(s)
-        p.v_mov_b32_e32(vT0, sLDS)
-        p.ds_read_b32(vSWP, vT0, mods=f"offset:{SSWP + (s % NR) * 32}")
-        p.s_waitcnt("lgkmcnt(0)")
+        p.v_mov_b32_e32(vSWP, sLDS)
+        p.ds_read_b32(vSWP, vSWP, mods=f"offset:{SSWP + (s % NR) * 32}")
+        if early:
+            self.swizzle_b(s, blocks[0], U[0])
+            if hook:
+                hook()
+            p.s_waitcnt("lgkmcnt(4)")
+        else:
+            p.s_waitcnt("lgkmcnt(0)")
+        if role == "nxt":
+            self.stamp(3)
         p.v_cmp_eq_u32_e32(VCC, 0, vSWP)
         p.s_cbranch_vccz(L_slow)
         p.label(L_back)
@@ -373,7 +449,10 @@ class Gen:
                 p.ds_read_b128(ACC(Ig, take), vT1, mods=f"offset:{NBUF + (s % NR) * 4096 + Ig * 1024}")
         for k, J in enumerate(blocks):
             if k == 0:
-                self.swizzle_b(s, J, U[0])
+                if not early:
+                    self.swizzle_b(s, J, U[0])
+                    if hook:
+                        hook()
                 self.fix_n(s)
             if k + 1 < len(blocks):
                 self.swizzle_b(s, blocks[k + 1], U[(k + 1) & 1])
@@ -450,10 +529,24 @@ class Gen:
             p.s_mov_b64(EXEC, -1)
             p.s_waitcnt("lgkmcnt(0)")
             p.label(L_skip)
-        for role, wv in roles:           # back to where this wave came from
+        labels = []                      # back to where this wave came from (B operands requested early are stale now)
+        for role, wv, J0 in roles:
+            L = p.newlabel(f"X{t}_{role}")
+            labels.append((L, role, J0))
             p.s_cmp_eq_u32(sW, wv)
-            p.s_cbranch_scc1(f"S{t}_{role}_swapped")
+            p.s_cbranch_scc1(L)
+        if "earlyswz" in self.opts:
+            self.swizzle_b(t, 0, U[0])
+            p.s_waitcnt("lgkmcnt(0)")
         p.s_branch(f"S{t}_oth_swapped")
+        for L, role, J0 in labels:
+            p.label(L)
+            if "earlyswz" in self.opts:
+                self.swizzle_b(t, J0, U[0])
+                p.s_waitcnt("lgkmcnt(0)")
+            if role == "nxt" and ("hoist" in self.opts or "preaddr" in self.opts):
+                self.factor_addresses()          # v89..v92 held them; the distances went through the same registers
+            p.s_branch(f"S{t}_{role}_swapped")
 
     def take_addr(self):
         """vT1 = base + rowl * 64 + j * 16, rowl = 4 b + i  (panel block rows in the X layout)"""
@@ -467,7 +560,37 @@ class Gen:
         p.v_add_u32_e32(vT1, sLDS, vT1)
 
     # ------------------------------------------------------------------ panel factorisation (one wave)
-    def factor_panel(self, t, J):
+    def factor_addresses(self):
+        """LDS addresses of the factorisation in v89..v92 (free between the flag read and the factorisation's own
+        temporaries): panel write (X layout -> row-major, stride 80 B), lane-per-row read, N write, base."""
+        p = self.p
+        p.v_lshrrev_b32_e32(vT1, 4, vLANE)                  # i
+        p.v_bfe_u32(vT2, vLANE, 2, 2)                       # b
+        p.v_lshl_add_u32(vT1, vT2, 2, vT1)                  # rowl
+        p.v_and_b32_e32(vT2, 3, vLANE)
+        p.v_lshlrev_b32_e32(vT2, 4, vT2)                    # j * 16
+        p.v_mul_u32_u24_e32(vT0, 80, vT1)
+        p.v_add_u32_e32(vT0, vT0, vT2)
+        p.v_add_u32_e32(vT0, sLDS, vT0)                     # vT0: Pbuf[(16 Ig + rowl) * 5 + j]
+        p.v_mul_u32_u24_e32(vT1, 80, vLANE)
+        p.v_add_u32_e32(vT1, sLDS, vT1)                     # vT1: Pbuf[lane * 5]
+        p.v_lshl_add_u32(vT2, vLANE, 6, sLDS)               # vT2: Nbuf[lane * 4]
+        p.v_mov_b32_e32(vT3, sLDS)                          # vT3: base
+
+    def write_constants(self):
+        """16 B of zeros and the pair (-1.0, 0.0) in the (otherwise unused) SROW region, by the wave that factors panel 0"""
+        p = self.p
+        p.v_mov_b32_e32(vT0, sLDS)
+        for k in range(4):
+            p.v_mov_b32_e32(V(80 + k), 0)
+        p.ds_write_b128(vT0, V(80, 4), mods=f"offset:{SROW}")
+        p.v_mov_b32_e32(V(84), 0)
+        p.v_mov_b32_e32(V(85), 0xBFF00000)
+        p.v_mov_b32_e32(V(86), 0)
+        p.v_mov_b32_e32(V(87), 0)
+        p.ds_write_b128(vT0, V(84, 4), mods=f"offset:{SROW + 16}")
+
+    def factor_panel(self, t, J, have_addresses=False):
         """Panel t = register block J of this wave -> LDS -> lane per row; four pivot steps; N_t and the interchange
         record -> LDS.  Mirrors factor_panel of tf_inv.hip:368-508 operation for operation."""
         p = self.p
@@ -475,34 +598,51 @@ class Gen:
         PV = P[:3]                                          # pivot row quads (three columns)
         vPR, vNW, vZ, vZERO = P[3].sub(0), P[3].sub(1), P[3].sub(2), P[3].sub(3)
         x = NQ
-        # X layout -> row-major panel (stride 80 B): Pbuf[(16 Ig + rowl) * 5 + j]
-        vPW = vT0
-        p.v_lshrrev_b32_e32(vT1, 4, vLANE)                  # i
-        p.v_bfe_u32(vT2, vLANE, 2, 2)                       # b
-        p.v_lshl_add_u32(vT1, vT2, 2, vT1)                  # rowl
-        p.v_and_b32_e32(vT2, 3, vLANE)
-        p.v_lshlrev_b32_e32(vT2, 4, vT2)                    # j * 16
-        p.v_mul_u32_u24_e32(vPW, 80, vT1)
-        p.v_add_u32_e32(vPW, vPW, vT2)
-        p.v_add_u32_e32(vPW, sLDS, vPW)
-        for Ig in range(4):
-            p.ds_write_b128(vPW, P[Ig], mods=f"offset:{PBUF + Ig * 1280}")
-        p.v_mul_u32_u24_e32(vT1, 80, vLANE)
-        p.v_add_u32_e32(vT1, sLDS, vT1)                     # lane-per-row address (copied into vPR below)
-        for jj in range(4):
-            p.ds_read_b128(x[jj], vT1, mods=f"offset:{PBUF + 16 * jj}")
-        p.s_waitcnt("lgkmcnt(0)")
-        # the panel block's registers are free now: addresses and constants live there
-        p.v_mov_b32_e32(vPR, vT1)
-        p.v_lshlrev_b32_e32(vNW, 6, vLANE)
-        p.v_add_u32_e32(vNW, sLDS, vNW)
-        p.v_mov_b32_e32(vZ, sLDS)
-        p.v_mov_b32_e32(vZERO, 0)
-        p.s_mov_b64(sOK, -1)
+        if not have_addresses:
+            self.factor_addresses()
+        # (the panel block comes straight out of the matrix pipe: nine wait states between an MFMA and an LDS store of
+        # its result -- the scalar initialisations and one s_nop fill them)
+        p.s_mov_b32(sBAD, 0)
+        p.s_mov_b32(S(67), 0)
         for k in range(4):
             p.s_mov_b32(sRS[k], 0)
+        for Ig in range(4):
+            if Ig == 3 and have_addresses:
+                p.s_nop(0)
+            p.ds_write_b128(vT0, P[Ig], mods=f"offset:{PBUF + Ig * 1280}")
         for jj in range(4):
-            self.pivot_column(t, jj, x, PV, vPR, vZ)
+            p.ds_read_b128(x[jj], vT1, mods=f"offset:{PBUF + 16 * jj}")
+        # the panel block's registers are free now: addresses and constants live there
+        p.v_mov_b32_e32(vPR, vT1)
+        p.v_mov_b32_e32(vNW, vT2)
+        p.v_mov_b32_e32(vZ, vT3)
+        p.v_mov_b32_e32(vZERO, 0)
+        p.s_waitcnt("lgkmcnt(0)")
+        self.stamp(5)
+        if "spec" in self.opts:
+            sFLAG = S(58, 2)
+            L_redo, L_cols = f"F{t}_redo", f"F{t}_cols"
+            p.s_mov_b64(sFLAG, 0)
+            for jj in range(4):
+                self.pivot_column_rl(t, jj, x, vPR, vZ, spec=True)
+            p.s_cmp_lg_u64(sFLAG, 0)
+            p.s_cbranch_scc1(L_redo)
+            p.label(L_cols)
+
+            def redo():
+                # some column wanted a row interchange (or met a pivot that is not > 0): the panel again, from the copy
+                # the transposition left in LDS (the speculative columns touch registers only), by the careful code
+                p.label(L_redo)
+                for jj in range(4):
+                    p.ds_read_b128(x[jj], vPR, mods=f"offset:{PBUF + 16 * jj}")
+                p.s_waitcnt("lgkmcnt(0)")
+                for jj in range(4):
+                    self.pivot_column_rl(t, jj, x, vPR, vZ, spec=False, tag="r")
+                p.s_branch(L_cols)
+            self.cold.append(redo)
+        else:
+            for jj in range(4):
+                self.pivot_column(t, jj, x, PV, vPR, vZ)
         # N_t
         for jj in range(4):
             p.ds_write_b128(vNW, x[jj], mods=f"offset:{NBUF + (t % NR) * 4096 + 16 * jj}")
@@ -517,12 +657,17 @@ class Gen:
         p.label(L_recd)
         # zero / NaN pivot: one test per panel
         L_bad, L_badd = f"F{t}_bad", f"F{t}_badd"
-        p.s_and_b64(sM1, sOKC[0], sOKC[1])
-        p.s_and_b64(sM1, sM1, sOKC[2])
-        p.s_and_b64(sM1, sM1, sOKC[3])
-        p.s_cmp_eq_u64(sM1, EXEC)
-        p.s_cbranch_scc0(L_bad)
+        if "rlpiv" in self.opts:
+            p.s_cmp_lg_u32(sBAD, 0)
+            p.s_cbranch_scc1(L_bad)
+        else:
+            p.s_and_b64(sM1, sOKC[0], sOKC[1])
+            p.s_and_b64(sM1, sM1, sOKC[2])
+            p.s_and_b64(sM1, sM1, sOKC[3])
+            p.s_cmp_eq_u64(sM1, EXEC)
+            p.s_cbranch_scc0(L_bad)
         p.label(L_badd)
+        self.stamp(7)
 
         def cold():
             p.label(L_rec)
@@ -534,13 +679,16 @@ class Gen:
             p.s_branch(L_recd)
             p.label(L_bad)
             # bad = 1 + first column whose |pivot|^2 is not > 0; recorded if info is still 0
-            p.s_mov_b32(sT0, 4 * t + 4)
-            for k in (2, 1, 0):
-                L = p.newlabel(f"F{t}_b")
-                p.s_cmp_eq_u64(sOKC[k], EXEC)
-                p.s_cbranch_scc1(L)
-                p.s_mov_b32(sT0, 4 * t + k + 1)
-                p.label(L)
+            if "rlpiv" in self.opts:
+                p.s_mov_b32(sT0, sBAD)
+            else:
+                p.s_mov_b32(sT0, 4 * t + 4)
+                for k in (2, 1, 0):
+                    L = p.newlabel(f"F{t}_b")
+                    p.s_cmp_eq_u64(sOKC[k], EXEC)
+                    p.s_cbranch_scc1(L)
+                    p.s_mov_b32(sT0, 4 * t + k + 1)
+                    p.label(L)
             p.ds_read_b32(vT0, vZ, mods=f"offset:{SINFO}")
             p.s_waitcnt("lgkmcnt(0)")
             p.v_readfirstlane_b32(sT1, vT0)
@@ -567,27 +715,145 @@ class Gen:
         p.v_fma_f64(fIVR, fIVR, fE, fIVR)
         p.v_fma_f64(fIVI, fIVI, fE, fIVI)
 
-    def pivot_column(self, t, jj, x, PV, vPR, vZ):
+    def constants_to_pivot_lane(self, col, jj, x, vZ):
+        """lane `col` <- zeroed row and the multiplier source (-1, 0): its eliminated row is then 1/pivot times the pivot
+        row and its column jj is 1/pivot, from the same instructions as every other lane's"""
         p = self.p
+        p.s_lshl_b64(EXEC, 1, col)
+        for j2 in range(4):
+            p.ds_read_b128(x[j2], vZ, mods=f"offset:{SROW + (16 if j2 == jj else 0)}")
+        p.s_mov_b64(EXEC, -1)
+
+    def pivot_column_rl(self, t, jj, x, vPR, vZ, spec=False, tag=""):
+        """pivot column with the pivot row in SGPRs (v_readlane): no LDS traffic on the common path.  The readlanes are
+        independent of the reciprocal's dependent chain and are placed in its gaps (in-order issue)."""
+        p = self.p
+        col = 4 * t + jj
+        others = [j2 for j2 in range(4) if j2 != jj]
+        spv = {j2: (PVS[2 * k], PVS[2 * k + 1]) for k, j2 in enumerate(others)}
+        xr, xi = RE(x[jj]), IM(x[jj])
+        L_search, L_elim, L_badc, L_badcd = (f"F{t}_{jj}{tag}_{n}" for n in ("search", "elim", "badc", "badcd"))
+        sFLAG = S(58, 2)
+        rl = []                                              # the twelve pivot-row readlanes, issued in the gaps below
+        for j2 in others:
+            for half, src in ((0, RE(x[j2])), (1, IM(x[j2]))):
+                for d in range(2):
+                    rl.append((spv[j2][half].sub(d), src.sub(d)))
+
+        def gap(n):
+            for _ in range(n):
+                if rl:
+                    dst, src = rl.pop(0)
+                    p.v_readlane_b32(dst, src, col)
+        p.v_readlane_b32(sPR.sub(0), xr.sub(0), col)
+        p.v_readlane_b32(sPR.sub(1), xr.sub(1), col)
+        p.v_readlane_b32(sPI.sub(0), xi.sub(0), col)
+        p.v_readlane_b32(sPI.sub(1), xi.sub(1), col)
+        p.v_add_f64(fCAND, Abs(xr), Abs(xi))
+        gap(1)
+        p.v_mov_b64_e32(fDC, sPI)
+        p.v_mul_f64(fDD, sPI, sPI)
+        gap(1)
+        p.v_add_f64(fDC, Abs(sPR), Abs(fDC))
+        p.v_fma_f64(fDD, sPR, sPR, fDD)
+        gap(1)
+        p.v_mul_f64(fCAND, sTAU, fCAND)
+        p.v_rcp_f64_e32(fY, fDD)
+        gap(2)
+        p.s_lshl_b64(sVALID, -1, col)
+        p.v_cmp_gt_f64_e32(VCC, fCAND, fDC)
+        p.v_fma_f64(fE, Neg(fDD), fY, 1.0)
+        gap(2)
+        p.s_and_b64(VCC, VCC, sVALID)
+        p.v_fma_f64(fY, fE, fY, fY)
+        gap(1)
+        if spec:
+            p.s_or_b64(sFLAG, sFLAG, VCC)
+        else:
+            p.s_cbranch_vccnz(L_search)
+        p.v_fma_f64(fE, Neg(fDD), fY, 1.0)
+        gap(2)
+        p.v_mul_f64(fIVR, sPR, fY)
+        p.v_mul_f64(fIVI, fY, Neg(sPI))
+        gap(2)
+        p.v_fma_f64(fIVR, fIVR, fE, fIVR)
+        p.v_fma_f64(fIVI, fIVI, fE, fIVI)
+        gap(12)
+        if not spec:
+            p.label(L_elim)
+        p.v_cmp_lt_f64_e32(VCC, 0, fDD)
+        p.v_mul_f64(fMR, xr, Neg(fIVR))
+        p.v_mul_f64(fMI, xi, Neg(fIVR))
+        if spec:
+            p.s_andn2_b64(sM1, EXEC, VCC)
+            p.s_or_b64(sFLAG, sFLAG, sM1)
+        else:
+            p.s_cbranch_vccz(L_badc)
+            p.label(L_badcd)
+        self.stamp(6)
+        p.v_fma_f64(fMR, xi, fIVI, fMR)
+        p.v_fma_f64(fMI, Neg(xr), fIVI, fMI)
+        p.s_lshl_b64(EXEC, 1, col)
+        p.v_mov_b64_e32(fMR, fIVR)
+        p.v_mov_b64_e32(fMI, fIVI)
+        for j2 in others:
+            p.v_mul_f64(RE(x[j2]), RE(x[j2]), 0)
+            p.v_mul_f64(IM(x[j2]), IM(x[j2]), 0)
+        p.s_mov_b64(EXEC, -1)
+        order = sorted(others, key=lambda j2: (j2 != jj + 1, j2))      # the next pivot column first
+        for j2 in order:
+            a = x[j2]
+            pr_, pi_ = spv[j2]
+            p.v_fma_f64(RE(a), fMR, pr_, RE(a))
+            p.v_fma_f64(IM(a), fMR, pi_, IM(a))
+            p.v_fma_f64(RE(a), Neg(fMI), pi_, RE(a))
+            p.v_fma_f64(IM(a), fMI, pr_, IM(a))
+        p.v_mov_b64_e32(xr, fMR)
+        p.v_mov_b64_e32(xi, fMI)
+        self.stamp(7)
+        if spec:
+            return
+
+        def cold():
+            # |pivot|^2 not > 0 (zero or NaN): remember the first such column (1-based), carry on
+            p.label(L_badc)
+            p.s_cmp_lg_u32(sBAD, 0)
+            p.s_cbranch_scc1(L_badcd)
+            p.s_mov_b32(sBAD, col + 1)
+            p.s_branch(L_badcd)
+        self.cold.append(cold)
+        if self.with_slow:
+            self.cold.append(lambda: self.search_cold(t, jj, x, spv, vPR, vZ, L_search, L_elim))
+        else:
+            self.cold.append(lambda: (p.label(L_search), p.s_endpgm()))
+
+    def pivot_column(self, t, jj, x, PV, vPR, vZ):
+        if "rlpiv" in self.opts:
+            return self.pivot_column_rl(t, jj, x, vPR, vZ)
+        p = self.p
+        ldsconst = "ldsconst" in self.opts
         col = 4 * t + jj
         others = [j2 for j2 in range(4) if j2 != jj]
         pv = {j2: PV[k] for k, j2 in enumerate(others)}
         xr, xi = RE(x[jj]), IM(x[jj])
         L_search, L_elim = f"F{t}_{jj}_search", f"F{t}_{jj}_elim"
-        # diagonal element (wave-uniform)
+        # diagonal element (wave-uniform); every row's |re| + |im| (izamax metric) while lane `col` still holds its row
         p.v_readlane_b32(sPR.sub(0), xr.sub(0), col)
         p.v_readlane_b32(sPR.sub(1), xr.sub(1), col)
         p.v_readlane_b32(sPI.sub(0), xi.sub(0), col)
         p.v_readlane_b32(sPI.sub(1), xi.sub(1), col)
+        p.v_add_f64(fCAND, Abs(xr), Abs(xi))
         # the pivot row (if the diagonal is kept): lane `col` publishes its other three columns, everybody reads them
         p.s_lshl_b64(EXEC, 1, col)
         for j2 in others:
             p.ds_write_b128(vZ, x[j2], mods=f"offset:{PBUF + col * 80 + 16 * j2}")
+        if ldsconst:
+            for j2 in range(4):
+                p.ds_read_b128(x[j2], vZ, mods=f"offset:{SROW + (16 if j2 == jj else 0)}")
         p.s_mov_b64(EXEC, -1)
         for j2 in others:
             p.ds_read_b128(pv[j2], vZ, mods=f"offset:{PBUF + col * 80 + 16 * j2}")
-        # |re| + |im| of every candidate row against the diagonal (izamax metric), reciprocal started at once
-        p.v_add_f64(fCAND, Abs(xr), Abs(xi))
+        # candidates against the diagonal, reciprocal of the diagonal started at once
         p.v_mov_b64_e32(fDC, sPI)
         p.v_mul_f64(fDD, sPI, sPI)
         p.v_add_f64(fDC, Abs(sPR), Abs(fDC))
@@ -607,19 +873,23 @@ class Gen:
         p.v_fma_f64(fIVI, fIVI, fE, fIVI)
         p.label(L_elim)
         p.v_cmp_gt_f64_e64(sOKC[jj], fDD, 0)
+        if ldsconst:
+            p.s_waitcnt("lgkmcnt(0)")
+        self.stamp(6)
         # multiplier mu = -x_jj / pivot; the pivot row's lane takes 1 / pivot on a zeroed row
         p.v_mul_f64(fMR, xr, Neg(fIVR))
         p.v_mul_f64(fMI, xi, Neg(fIVR))
         p.v_fma_f64(fMR, xi, fIVI, fMR)
         p.v_fma_f64(fMI, Neg(xr), fIVI, fMI)
-        p.s_lshl_b64(EXEC, 1, col)
-        p.v_mov_b64_e32(fMR, fIVR)
-        p.v_mov_b64_e32(fMI, fIVI)
-        for j2 in others:
-            p.v_mul_f64(RE(x[j2]), RE(x[j2]), 0)
-            p.v_mul_f64(IM(x[j2]), IM(x[j2]), 0)
-        p.s_mov_b64(EXEC, -1)
-        p.s_waitcnt("lgkmcnt(0)")
+        if not ldsconst:
+            p.s_lshl_b64(EXEC, 1, col)
+            p.v_mov_b64_e32(fMR, fIVR)
+            p.v_mov_b64_e32(fMI, fIVI)
+            for j2 in others:
+                p.v_mul_f64(RE(x[j2]), RE(x[j2]), 0)
+                p.v_mul_f64(IM(x[j2]), IM(x[j2]), 0)
+            p.s_mov_b64(EXEC, -1)
+            p.s_waitcnt("lgkmcnt(0)")
         order = sorted(others, key=lambda j2: (j2 != jj + 1, j2))      # the next pivot column first
         for j2 in order:
             a = x[j2]
@@ -629,6 +899,7 @@ class Gen:
             p.v_fma_f64(IM(a), fMI, RE(pv[j2]), IM(a))
         p.v_mov_b64_e32(xr, fMR)
         p.v_mov_b64_e32(xi, fMI)
+        self.stamp(7)
         if self.with_slow:
             self.cold.append(lambda: self.search_cold(t, jj, x, pv, vPR, vZ, L_search, L_elim))
         else:
@@ -643,6 +914,17 @@ class Gen:
         key = V(88)
         L_same = p.newlabel(f"F{t}_{jj}_same")
         p.label(L_search)
+        if "ldsconst" in self.opts:
+            # lane `col` already received the constants: give it its row back (columns j2 != jj from the published slot,
+            # column jj = the diagonal element that sits in sPR / sPI)
+            p.s_waitcnt("lgkmcnt(0)")
+            p.s_lshl_b64(EXEC, 1, col)
+            for j2 in pv:
+                p.ds_read_b128(x[j2], vZ, mods=f"offset:{PBUF + col * 80 + 16 * j2}")
+            p.v_mov_b64_e32(xr, sPR)
+            p.v_mov_b64_e32(xi, sPI)
+            p.s_mov_b64(EXEC, -1)
+            p.s_waitcnt("lgkmcnt(0)")
         p.v_add_f64(fCAND, Abs(xr), Abs(xi))
         p.v_cvt_f32_f64_e32(key, fCAND)
         p.s_nop(1)
@@ -690,12 +972,30 @@ class Gen:
         p.s_mul_i32(sT0, sRSTAR, 80)
         p.s_add_i32(sT0, sT0, sLDS)
         p.v_mov_b32_e32(V(88), sT0)
+        if "rlpiv" in self.opts:
+            # into SGPRs: broadcast reads into the (dead) reciprocal temporaries, then readfirstlane
+            for j2, (pr_, pi_) in pv.items():
+                p.ds_read_b128(V(80, 4), V(88), mods=f"offset:{PBUF + 16 * j2}")
+                p.s_waitcnt("lgkmcnt(0)")
+                for d in range(2):
+                    p.v_readfirstlane_b32(pr_.sub(d), V(80 + d))
+                    p.v_readfirstlane_b32(pi_.sub(d), V(82 + d))
+            pv = {}
         for j2 in pv:
             p.ds_read_b128(pv[j2], V(88), mods=f"offset:{PBUF + 16 * j2}")
+        if "ldsconst" in self.opts:
+            self.constants_to_pivot_lane(col, jj, x, vZ)
         p.s_waitcnt("lgkmcnt(0)")
         p.s_branch(L_elim)
         # the maximum sits on the diagonal after all (ties / threshold): finish the speculative reciprocal
         p.label(L_same)
+        if "ldsconst" in self.opts:
+            self.constants_to_pivot_lane(col, jj, x, vZ)
+        if "rlpiv" in self.opts:          # the branch cut the pivot row's readlanes short: all twelve again
+            for j2, (pr_, pi_) in pv.items():
+                for d in range(2):
+                    p.v_readlane_b32(pr_.sub(d), RE(x[j2]).sub(d), col)
+                    p.v_readlane_b32(pi_.sub(d), IM(x[j2]).sub(d), col)
         p.v_fma_f64(fE, Neg(fDD), fY, 1.0)
         p.v_mul_f64(fIVR, sPR, fY)
         p.v_mul_f64(fIVI, fY, Neg(sPI))
@@ -707,19 +1007,32 @@ class Gen:
     def build(self):
         p = self.p
         self.prologue()
+        self.stamp_init()
         if self.build_af:
             self.build_a()
+        self.stamp(0)
         self.lane_constants()
         # panel 0 by wave 0
         L0 = "P0_done"
         p.s_cmp_lg_u32(sW, 0)
         p.s_cbranch_scc1(L0)
-        p.s_setprio(3)
+        self.setprio(3)
+        if "ldsconst" in self.opts:
+            self.write_constants()
+        self.stamp(2)
         self.factor_panel(0, 0)
-        p.s_setprio(0)
+        self.setprio(0)
         p.label(L0)
+        if "preaddr" in self.opts:
+            L_p1 = "P1_addr"
+            p.s_cmp_lg_u32(sW, 1)
+            p.s_cbranch_scc1(L_p1)
+            self.factor_addresses()
+            p.label(L_p1)
         p.s_waitcnt("lgkmcnt(0)")
+        self.stamp(2)
         p.s_barrier()
+        self.stamp(1)
         for s in range(NSTEP):
             self.step(s)
         L_exit = "K3A_exit"
@@ -730,8 +1043,20 @@ class Gen:
         return p
 
 
-def emit_inc(path):
-    g = Gen(for_text=True)
+def _emit_macro(f, name, extra_params, lines, extra_outs, s_hi):
+    lo, _ = CLOBBER_S
+    f.write(f"#define {name}(ACC, ARX, TW, P, W, TAU, LDSBASE{extra_params}) \\\n  asm volatile( \\\n")
+    for ln in lines:
+        f.write('    "' + ln.replace('"', '\\"') + '\\n" \\\n')
+    outs = ", ".join(f'"={{v[{2 * k}:{2 * k + 1}]}}"(ACC[{k}])' for k in range(32))
+    f.write(f"    : {outs}{extra_outs} \\\n")
+    f.write('    : "s"(ARX), "s"(TW), "s"(P), "s"(W), "s"(TAU), "s"(LDSBASE) \\\n')
+    clob = ", ".join(f'"v{k}"' for k in range(64, 96)) + ", " + ", ".join(f'"s{k}"' for k in range(lo, s_hi))
+    f.write(f'    : {clob}, "vcc", "scc", "memory")\n')
+
+
+def emit_inc(path, opts=None):
+    g = Gen(for_text=True, opts=opts)
     prog = g.build()
     lines = prog.text_lines(label_prefix="K3A_%=_")
     lo, hi = CLOBBER_S
@@ -742,18 +1067,26 @@ def emit_inc(path):
                           ("SSWP", SSWP), ("SINFO", SINFO), ("LDS_TOTAL", LDS_TOTAL)):
             f.write(f"#define K3A_{name} {val}\n")
         f.write(f"#define K3A_NUM_INSTRUCTIONS {sum(1 for l in lines if l.startswith('  '))}\n")
-        f.write("#define K3A_BODY(ACC, ARX, TW, P, W, TAU, LDSBASE) \\\n  asm volatile( \\\n")
-        for ln in lines:
-            f.write('    "' + ln.replace('"', '\\"') + '\\n" \\\n')
-        outs = ", ".join(f'"={{v[{2 * k}:{2 * k + 1}]}}"(ACC[{k}])' for k in range(32))
-        f.write(f"    : {outs} \\\n")
-        f.write('    : "s"(ARX), "s"(TW), "s"(P), "s"(W), "s"(TAU), "s"(LDSBASE) \\\n')
-        clob = ", ".join(f'"v{k}"' for k in range(64, 96)) + ", " + ", ".join(f'"s{k}"' for k in range(lo, hi))
-        f.write(f'    : {clob}, "vcc", "scc", "memory")\n')
+        _emit_macro(f, "K3A_BODY", "", lines, "", hi)
+        # the diagnostic build's body: the same stream with s_memtime stamps; the five extra outputs are the phase sums
+        # (A(f) build, factorisation, barrier wait, rest of the loop) and the last stamp, pinned to s[92:99], s[90:91]
+        gs = Gen(for_text=True, opts=sorted(g.opts | {"stamps"}))
+        for k in range(5):            # inputs move up by five operand numbers
+            pass
+        gs.in_arx, gs.in_tw = Reg("op", 37, 2), Reg("op", 38, 2)
+        gs.in_p, gs.in_w, gs.in_tau, gs.in_lds = Reg("op", 39), Reg("op", 40), Reg("op", 41, 2), Reg("op", 42)
+        slines = gs.build().text_lines(label_prefix="K3A_%=_")
+        souts = "".join(f', "={{s[{92 + 2 * k}:{93 + 2 * k}]}}"(T{k})' for k in range(4)) + ', "={s90}"(TLAST)'
+        _emit_macro(f, "K3A_BODY_STAMPED", ", T0, T1, T2, T3, TLAST", slines, souts, 90)
     return len(lines)
 
 
 if __name__ == "__main__":
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tf_inv64_body.inc")
-    n = emit_inc(os.path.normpath(out))
-    print(f"wrote {os.path.normpath(out)}: {n} lines")
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tf_inv64_body.inc"))
+    ap.add_argument("--opts", default=None, help="comma-separated stream options (default: Gen.DEFAULT_OPTS); 'none' = plain")
+    a = ap.parse_args()
+    opts = None if a.opts is None else [o for o in a.opts.split(",") if o and o != "none"]
+    n = emit_inc(os.path.normpath(a.out), opts)
+    print(f"wrote {os.path.normpath(a.out)}: {n} lines, options {sorted(Gen(True, opts=opts).opts)}")

@@ -130,11 +130,11 @@ struct NormLds {
 
 // den[item][:] from the row sums of all frequencies; every thread of the workgroup; `lds`: NormLds doubles.
 template <int NT>
-__device__ __forceinline__ void window_denominators(const TfArgs& a, int item, double* lds) {
+__device__ __forceinline__ void window_denominators(const TfArgs& a, int item, double* lds, const int tid) {
   constexpr int MP = 16 * NT;
   using N = NormLds<NT>;
   double* dpart = lds + NT * N::FC * N::TS;      // [4][MP] partial sums over the four quarters of the grid
-  const int F = a.F, t = threadIdx.x;
+  const int F = a.F, t = tid;
   const int ty = t / MP, tx = t - ty * MP;         // 64 * NT / MP = 4 thread rows
   const double* rs = a.rowsum + (size_t)item * F * MP + tx;
   const int fq = (F + 3) >> 2;
@@ -159,13 +159,13 @@ __device__ __forceinline__ void window_denominators(const TfArgs& a, int item, d
 
 // Output row i of window `item`; every thread of the workgroup, no workgroup barrier inside.
 template <int NT>
-__device__ __forceinline__ void normalise_row(const TfArgs& a, int item, int i, double* lds) {
+__device__ __forceinline__ void normalise_row(const TfArgs& a, int item, int i, double* lds, const int tid) {
   constexpr int MP = 16 * NT;
   using N = NormLds<NT>;
   constexpr int FC = N::FC, JC = N::JC, TS = N::TS;
   constexpr int J2 = JC / 2, FR = 64 / J2, NL = FC / FR, NQ = JC / 8, NJC = MP / JC, D = 4;
   const int F = a.F, m = a.m;
-  const int l = threadIdx.x & 63, wv = uni(threadIdx.x >> 6);
+  const int l = tid & 63, wv = uni(tid >> 6);
   double* tile = lds + wv * (FC * TS);     // this wave's private tile
   const double r = 1.0 / __hip_atomic_load(a.den + (size_t)item * MP + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // wave-trips of this row: (16-frequency chunk, JC-column chunk), dealt round-robin to the waves
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
   const int n = a.missed[0];
   for (int k = blockIdx.x; k < n; k += gridDim.x) {
     const int e = a.missed[1 + k];
-    normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds);
+    normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, (int)threadIdx.x);
     __syncthreads();
   }
 }
@@ -252,6 +252,9 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
   int lo;
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
   const int rowo = 4 * ((lo >> 2) & 3) + (lo >> 4), jo = lo & 3;
+  // thread index rebuilt from the (scalar) wave index and the opaque lane id: nothing here depends on the register the
+  // hardware delivered threadIdx.x in, which a hand-written body in front of this function has overwritten
+  const int tid = 64 * wv + lo;
   int oc[4];      // output column of stored column c is orig[c] (last written before the final barrier)
 #pragma unroll
   for (int Jl = 0; Jl < 4; ++Jl) oc[Jl] = s_orig[4 * (Jl * NT + w) + jo];
@@ -325,7 +328,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
         });
         __syncthreads();
 #pragma unroll
-        for (int idx = threadIdx.x; idx < CNT; idx += 64 * NT) {
+        for (int idx = tid; idx < CNT; idx += 64 * NT) {
           const int row = idx / C2, c2 = idx - row * C2;
           const f64x2 v = *reinterpret_cast<const f64x2*>(tile + row * TS + 2 * c2);
           store_sc1_b128(Pg + (size_t)(16 * G * pass + row) * a.F * MP + 2 * c2, v);
@@ -339,12 +342,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
       }
     }
   }
-#ifdef HMV_STAMP
-  HMV_T(6);
-  if (a.stamps && lo == 0) {
-    for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
-  }
-#endif
+  HMV_T(4);          // |H|^2, LDS transposition, stores issued
 
   // ---------------------------------------------------------------- fused normalisation (ffDTF)
   // This workgroup's |H|^2 and row sums were stored write-through (sc1).  Every storing wave drains its stores,
@@ -358,7 +356,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
       if (item < a.fuse_items) {                             // workgroup-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
           const int old = __hip_atomic_fetch_add(a.wcount + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int last = (old == a.F - 1) ? 1 : 0;
           if (last) {
@@ -368,18 +366,19 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
           s_info = last;
         }
         __syncthreads();
+        HMV_T(5);    // stores drained, matrix counted
         if (s_info != 0) {
-          window_denominators<NT>(a, item, nlds);
+          window_denominators<NT>(a, item, nlds, tid);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
-          if (threadIdx.x == 0) __hip_atomic_store(a.ready + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tid == 0) __hip_atomic_store(a.ready + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       // Rows f, f + F, ... of window item - lag are this workgroup's to normalise.
       const int wl = item - a.lag;
       if (wl >= 0 && wl < a.fuse_items && f < a.m) {         // workgroup-uniform
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
           // No acquire fence here (it costs ~7 us with four workgroups on the CU, 38 000 times per launch): the
           // flag and the denominator are read with device-scope (sc1) loads, and the |H|^2 rows with non-temporal
           // loads that bypass this CU's L1 -- every one of those lines was written write-through before ready[wl]
@@ -394,12 +393,19 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
           s_info = rdy;
         }
         __syncthreads();
+        HMV_T(6);    // denominators (rarely), flag of the window whose row is this workgroup's
         if (s_info != 0) {
-          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds);
+          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds, tid);
         }
       }
     }
   }
+#ifdef HMV_STAMP
+  HMV_T(7);          // the row
+  if (a.stamps && lo == 0) {
+    for (int k = 0; k < 8; ++k) a.stamps[(gw * NT + wv) * 8 + k] = tsum[k];
+  }
+#endif
 }
 
 // GEN = false: A(f) from the AR coefficients (the hot path).  GEN = true: the same inversion of arbitrary
@@ -800,7 +806,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
         }
       });
     }
-    HMV_T(4);
+    HMV_T(3);
     __builtin_amdgcn_sched_barrier(0);     // keep the next operand loads below the deferred MFMAs (VGPR budget)
     // ---- B. interchanges of step s, A operands of update s
     double nr[NG], ni[NG];
@@ -818,7 +824,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
         if (!is_nxt && !(w == own && Jl == Js)) update_block(sc, jc, nr, ni);
       }
     });
-    HMV_T(4);
+    HMV_T(3);
     __builtin_amdgcn_sched_barrier(0);
     // last in program order (the next owner skipped the slots above): the A operands are dead here, the
     // factorisation runs with only the accumulators live
@@ -828,7 +834,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
     HMV_T(2);
   });
 
-  HMV_T(5);
+  HMV_T(3);
   tf_outputs<NT, GEN>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, &s_info, s_det
 #ifdef HMV_STAMP
                       , tsum, tlast
@@ -844,15 +850,22 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
 // resident matrices cover; the compiler needs 128 registers for the body and spills ~1 700 at 96.
 // The stream is executed on a CPU emulator against NumPy, and its wait states / wait counts are checked there
 // (tests/test_k3_asm_cpu.py), because hipcc does neither inside an asm statement.
-#include "tf_inv64_body.inc"
+#ifndef HMV_K3A_INC
+#define HMV_K3A_INC "tf_inv64_body.inc"      // tools/dbg/k3a_variant.sh builds A/B variants from other option sets
+#endif
+#include HMV_K3A_INC
 #ifndef HMV_K3A_WGS
+#ifdef HMV_STAMP
+#define HMV_K3A_WGS 4      // the stamped body pins twelve more SGPRs: the compiler then needs spare VGPRs to park its own
+#else
 #define HMV_K3A_WGS 5
+#endif
 #endif
 static_assert(K3A_PBUF == 0 && K3A_NBUF == 16 * TfLds<4>::PBUF && K3A_RSUM == 16 * (TfLds<4>::TOTAL - TfLds<4>::RSUM),
               "LDS map of the generated body and of the epilogue disagree");
 
 __global__ void __launch_bounds__(256, HMV_K3A_WGS) tf_inv64_asm_kernel(TfArgs a) {
-  constexpr int NT = 4, MP = 64;
+  constexpr int NT = 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[K3A_LDS_TOTAL];
   int* s_orig = reinterpret_cast<int*>(lds + K3A_SORIG);
   int* s_flag = reinterpret_cast<int*>(lds + K3A_SINFO);
@@ -872,7 +885,28 @@ __global__ void __launch_bounds__(256, HMV_K3A_WGS) tf_inv64_asm_kernel(TfArgs a
   const double tau = a.tau;
   const unsigned ldsbase = (unsigned)(uintptr_t)lds;
   double acc[32];
+#ifdef HMV_STAMP
+  // the stamped stream keeps eight 32-bit phase sums (csrc/gen/k3gen.py, stamp()): folded into the common four here,
+  // written out in full behind the per-wave records (a.stamps + 8 * waves) for tools/k3_stamps.py
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, q0, q1, q2, q3;
+  unsigned tl32;
+  K3A_BODY_STAMPED(acc, arx, tw, p, w, tau, ldsbase, q0, q1, q2, q3, tl32);
+  {
+    const unsigned long long d[8] = {q0 & 0xffffffffull, q0 >> 32, q1 & 0xffffffffull, q1 >> 32,
+                                     q2 & 0xffffffffull, q2 >> 32, q3 & 0xffffffffull, q3 >> 32};
+    tsum[0] = d[0]; tsum[2] = d[1]; tsum[3] = d[2] + d[3] + d[4]; tsum[1] = d[5] + d[6] + d[7];
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    tlast = (now & ~0xffffffffull) | tl32;
+    if (tlast > now) tlast -= 0x100000000ull;
+    if (a.stamps && lane_id() == 0) {
+      unsigned long long* det = a.stamps + ((size_t)a.n_items * a.F * NT + (size_t)(gw * NT + wv)) * 8;
+      for (int k = 0; k < 8; ++k) det[k] = d[k];
+    }
+  }
+#else
   K3A_BODY(acc, arx, tw, p, w, tau, ldsbase);
+#endif
   double re[NT][4], im[NT][4];
 #pragma unroll
   for (int Ig = 0; Ig < 4; ++Ig)
@@ -883,9 +917,6 @@ __global__ void __launch_bounds__(256, HMV_K3A_WGS) tf_inv64_asm_kernel(TfArgs a
     }
   double2* smem = reinterpret_cast<double2*>(lds);
   double* rsum = reinterpret_cast<double*>(lds + K3A_RSUM);
-#ifdef HMV_STAMP
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-#endif
   tf_outputs<NT, false>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, s_flag, nullptr
 #ifdef HMV_STAMP
                         , tsum, tlast
@@ -975,11 +1006,17 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
       break;
     case 64:
       hipLaunchKernelGGL(ar_pack_kernel<4>, pgrid, dim3(256), 0, st, a.ar, arx, a.n_items, a.p);
+      if (tuning(5) > 0) {        // measurement knob: dynamic LDS nobody uses, to hold fewer workgroups per CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tf_inv64_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)tuning(5));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tf_inv_kernel<4, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tuning(5));
+      }
       // the hand-scheduled body has no A(f) output (asked for by the staged API only)
       if (tuning(3 /* HMV_TUNE_K3_FORM */) != 1 && a.A == nullptr)
-        hipLaunchKernelGGL(tf_inv64_asm_kernel, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(tf_inv64_asm_kernel, grid, dim3(256), (unsigned)tuning(5 /* HMV_TUNE_K3_LDS_PAD */), st, a);
       else
-        hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), (unsigned)tuning(5), st, a);
       break;
     default: return -1;
   }

@@ -21,6 +21,17 @@ from . import _lib
 __all__ = ["Engine", "default_engine", "SingularMatrixError", "validate_items"]
 
 
+# Pivot threshold of the per-frequency inverses of A(f) (K3): a row interchange happens only when some row's |re| + |im|
+# exceeds the diagonal's by more than a factor 1 / tau (threshold partial pivoting: multipliers bounded by 1 / tau).
+# tau = 1 is LAPACK's partial pivoting.  A(f) = I - sum_k A_k z_k is close to the identity; with tau = 1 nine per cent of
+# its pivot columns interchange two rows whose candidates differ by a few per cent -- an interchange that buys no
+# accuracy (max-norm distance to numpy.linalg.inv 2.2e-15 either way, measured on the north-star dyad) and costs every
+# wave of the workgroup a trip through LDS: K3 8.19 -> 7.64 ms at tau = 0.25, where 0.2 % of the columns still
+# interchange (profiles/r03_k3_ab_notes.md).  `Engine(pivot_tau=1.0)` or HYPERMVAR_PIVOT_TAU=1 restores LAPACK's rule;
+# the general complex inverse (partial coherence of arbitrary spectral matrices) always uses tau = 1.
+DEFAULT_PIVOT_TAU = 0.25
+
+
 class SingularMatrixError(np.linalg.LinAlgError):
     """Raised where the reference's np.linalg.solve / np.linalg.inv raise LinAlgError('Singular matrix')."""
 
@@ -53,7 +64,10 @@ def validate_items(x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Te
 
 
 class Engine:
-    def __init__(self, device=None, pivot_tau: float = 1.0, max_workspace_bytes: int = 24 << 30):
+    def __init__(self, device=None, pivot_tau: float | None = None, max_workspace_bytes: int = 24 << 30):
+        import os
+        if pivot_tau is None:
+            pivot_tau = float(os.environ.get("HYPERMVAR_PIVOT_TAU", DEFAULT_PIVOT_TAU))
         self.lib = _lib.load()                      # fails loudly when the HIP library is not built
         if not torch.cuda.is_available():
             raise RuntimeError("hypermvar needs a ROCm GPU (MI355X); there is no CPU fallback")
@@ -246,7 +260,7 @@ class Engine:
         info = self.empty(n_items * F, dtype=torch.int32)
         with torch.cuda.device(self.device):
             rc = self.lib.hmv_cinv_c128(Z.data_ptr(), n_items, m, F, Zi.data_ptr(), detph.data_ptr(), info.data_ptr(),
-                                        self.pivot_tau, self.stream())
+                                        1.0, self.stream())
         _lib.check(rc, "hmv_cinv_c128")
         return Zi, detph, info
 

@@ -100,14 +100,18 @@ def check_inverse(waves, lds, rot, A, tol=1e-9):
     return orig
 
 
-@pytest.fixture(scope="module")
-def inv_prog():
-    return K.Gen(for_text=False, build_af=False).build()
+VARIANTS = {"plain": (), "default": None, "ldsconst": ("earlyswz", "hoist", "ldsconst"),
+            "spec": ("earlyswz", "hoist", "rlpiv", "spec", "preaddr")}
 
 
-@pytest.fixture(scope="module")
-def full_prog():
-    return K.Gen(for_text=False, build_af=True).build()
+@pytest.fixture(scope="module", params=sorted(VARIANTS))
+def inv_prog(request):
+    return K.Gen(for_text=False, build_af=False, opts=VARIANTS[request.param]).build()
+
+
+@pytest.fixture(scope="module", params=sorted(VARIANTS))
+def full_prog(request):
+    return K.Gen(for_text=False, build_af=True, opts=VARIANTS[request.param]).build()
 
 
 def hazards(prog, waves, what):
@@ -190,9 +194,10 @@ def test_generated_text_is_current_and_assembles(tmp_path):
     if not os.path.exists(mc):
         pytest.skip("llvm-mc not available")
     import subprocess
-    prog = K.Gen(for_text=False).build()
-    src = tmp_path / "body.s"
-    src.write_text("\n".join(prog.text_lines()) + "\n")
-    r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", str(tmp_path / "body.o"), str(src)],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[:3000]
+    for name, opts in VARIANTS.items():
+        prog = K.Gen(for_text=False, opts=opts).build()
+        src = tmp_path / f"body_{name}.s"
+        src.write_text("\n".join(prog.text_lines()) + "\n")
+        r = subprocess.run([mc, "-arch=amdgcn", "-mcpu=gfx950", "-filetype=obj", "-o", str(tmp_path / "body.o"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stderr[:3000]
