@@ -477,9 +477,12 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     }
     if (rc) break;
     // the tiled form of K2 (asked for, or chosen for a large 64-channel chunk) as two half-batches
-    const bool tiled = (flags & HMV_FLAG_YW_TILED) || (!(flags & HMV_FLAG_YW_ONE_LAUNCH) && mp == 64 && c >= 128);
+    // K2: the Levinson-Whittle recursion unless an LDL^T form is asked for (or HMV_TUNE_YW_FORM = 1, which picks the
+    // LDL^T form by batch shape as before: the launch chain for large 64-channel chunks)
+    const bool ldl = (flags & (HMV_FLAG_YW_TILED | HMV_FLAG_YW_ONE_LAUNCH)) || hmv::tuning(HMV_TUNE_YW_FORM) == 1;
+    const bool tiled = (flags & HMV_FLAG_YW_TILED) || (ldl && !(flags & HMV_FLAG_YW_ONE_LAUNCH) && mp == 64 && c >= 128);
     const int64_t yw_flags = (flags & ~(int64_t)(HMV_FLAG_YW_TILED | HMV_FLAG_YW_ONE_LAUNCH)) |
-                             (tiled ? HMV_FLAG_YW_TILED : HMV_FLAG_YW_ONE_LAUNCH);
+                             (ldl ? (tiled ? HMV_FLAG_YW_TILED : HMV_FLAG_YW_ONE_LAUNCH) : 0);
     const int64_t c0 = (split && tiled && c >= 16) ? (c + 1) / 2 : c, c1 = c - c0;
     if (c1 > 0) {
       // fork: st1 may start once K1 is done.  Whatever happens on st1 afterwards, st0 joins it again before this call

@@ -46,11 +46,14 @@ struct YwArgs {
   double* V;                // [n_items][MP][MP]
   double* Vq_logdet;        // optional [n_items][p]: log det V_q for q = 1..p (model-order criterion)
   int* info;                // [n_items]
-  int tiled;                // 0: one workgroup per window, one launch;  1: one workgroup per tile, 18 launches;
-                            // -1: pick by batch shape (launch_yw)
+  int tiled;                // block LDL^T forms (yw_solve.hip): 0: one workgroup per window, one launch;  1: one workgroup
+                            // per tile, p + 2 launches;  -1: no form asked for -- the block Levinson-Whittle recursion
+                            // (yw_lwr.hip) unless HMV_TUNE_YW_FORM says otherwise
+  int only_guarded;         // internal: the one-launch LDL^T kernel re-solves only the windows the recursion flagged
 };
 long long yw_ws_tiles(int p);
 int launch_yw(const YwArgs& a, int m_pad, hipStream_t st);
+int launch_yw_lwr(const YwArgs& a, int m_pad, hipStream_t st);
 
 // ---- K3 transfer matrix inverse ---------------------------------------------------------------
 struct TfArgs {

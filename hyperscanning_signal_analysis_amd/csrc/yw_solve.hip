@@ -30,120 +30,12 @@
 // that owns the panel columns factors them lane-per-row, every wave applies the rank-4 update on the matrix pipe;
 // same scheme as K3, real, no pivoting).  The stage as a whole is bound by HBM traffic, not by the matrix pipe
 // (~14 MB of tile operands and results per window).
-#include "hmv_common.h"
-#include "hmv_kernels.h"
+#include "yw_common.h"
 #include <cstdlib>
 
 namespace hmv {
 
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
-#define HMV_WAVE_SYNC()                                     \
-  do {                                                      \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
-    __builtin_amdgcn_wave_barrier();                        \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
-  } while (0)
-
-__host__ __device__ inline long long yw_tri(int a, int b) { return (long long)a * (a + 1) / 2 + b; }
-__host__ __device__ inline long long yw_ws_tiles_d(int p) { return 2 * yw_tri(p + 1, 0) + 2 * (long long)p; }
 long long yw_ws_tiles(int p) { return yw_ws_tiles_d(p); }
-
-template <int NT>
-struct YwCfg {
-  static constexpr int MP = 16 * NT;
-  static constexpr int S = (MP <= 38) ? 38 : 70;   // >= MP and = 6 (mod 32)
-};
-
-// Cooperative inverse of the symmetric positive definite MP x MP tile stored row-major (stride S) in LDS
-// `Xs`, by the whole workgroup (same scheme as K3, real arithmetic, no pivoting): wave w < NT holds columns
-// 16w..16w+15 in the D layout; the wave that owns the 4 panel columns of block step s factors them in a
-// lane-per-row layout (pivots by v_readlane, Newton reciprocal), publishes N = M'[:, S] through LDS, and
-// after one barrier every wave runs its 4*NT MFMAs of the rank-4 update.  Must be called by all 256 threads.
-// dinv_out (global, may be null): the inverse;  logdet_out (global, may be null): log det of the tile.
-template <int NT, int S>
-__device__ __forceinline__ void spd_inverse_coop(const double* Xs, double* Pb, double* Nb2, int* s_info,
-                                                 double* s_ld, double* dinv_out, double* logdet_out, int info_base) {
-  constexpr int MP = 16 * NT, NI = 4 * NT, NSTEP = MP / 4;
-  const int l = lane_id();
-  const int w = uni(threadIdx.x >> 6);
-  const int i = l >> 4, cc = l & 15;
-  const bool active = (w < NT);
-  double m[NI];
-  if (active) {
-#pragma unroll
-    for (int I = 0; I < NI; ++I) m[I] = Xs[(4 * I + i) * S + 16 * w + cc];
-  }
-  double mypiv = 1.0;
-  static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int s = decltype(sc)::value;
-    constexpr int ws = s >> 2, q = s & 3;
-    double* Nb = Nb2 + (s & 1) * MP * 4;
-    if (w == ws) {
-      if ((cc >> 2) == q) {
-#pragma unroll
-        for (int I = 0; I < NI; ++I) Pb[(4 * I + i) * 4 + (cc & 3)] = m[I];
-      }
-      HMV_WAVE_SYNC();
-      double x[4];
-      {
-        const int r = (l < MP) ? l : 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) x[jj] = Pb[r * 4 + jj];
-      }
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int col = 4 * s + jj;
-        const double piv = readlane_f64(x[jj], col);
-        if (!(piv > 0.0) && l == 0 && *s_info == 0) *s_info = info_base + col + 1;
-        mypiv = (l == col) ? piv : mypiv;
-        double inv = __builtin_amdgcn_rcp(piv);                  // v_rcp_f64 seed + 2 Newton steps
-        inv = __builtin_fma(__builtin_fma(-piv, inv, 1.0), inv, inv);
-        inv = __builtin_fma(__builtin_fma(-piv, inv, 1.0), inv, inv);
-        double qv[4];
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) qv[j2] = (j2 == jj) ? inv : readlane_f64(x[j2], col) * inv;
-        const double f = x[jj];
-        const bool isp = (l == col);
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) {
-          const double base = (j2 == jj) ? 0.0 : x[j2];
-          const double nr = __builtin_fma(-f, qv[j2], base);
-          x[j2] = isp ? qv[j2] : nr;
-        }
-      }
-      if (l < MP) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) Nb[l * 4 + jj] = x[jj];
-      }
-    }
-    __syncthreads();
-    if (active) {
-      const double u = m[s];
-#pragma unroll
-      for (int I = 0; I < NI; ++I) {
-        double nv = Nb[(4 * I + (l & 3)) * 4 + (l >> 4)];
-        if (I == s) nv -= ((l & 3) == (l >> 4)) ? 1.0 : 0.0;
-        m[I] = mfma4(nv, u, m[I]);
-      }
-      if (w == ws && (cc >> 2) == q) {
-#pragma unroll
-        for (int I = 0; I < NI; ++I) m[I] = Nb[(4 * I + i) * 4 + (cc & 3)];
-      }
-    }
-  });
-  if (dinv_out && active) {
-#pragma unroll
-    for (int I = 0; I < NI; ++I) dinv_out[(size_t)(4 * I + i) * MP + 16 * w + cc] = m[I];
-  }
-  if (logdet_out) {          // pivots live on lane `col` of the wave that factored column `col`
-    double v = row16_sum_dpp(log(mypiv));
-    v = readlane_f64(v, 0) + readlane_f64(v, 16) + readlane_f64(v, 32) + readlane_f64(v, 48);
-    if (l == 0) s_ld[w] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *logdet_out = ((s_ld[0] + s_ld[1]) + s_ld[2]) + s_ld[3];
-  }
-}
 
 struct YwPtrs {
   const double* R;
@@ -219,6 +111,9 @@ __global__ void __launch_bounds__(256, VQ ? 2 : (MODE == 2 ? 4 : 3)) yw_window_k
     item = (long long)grp * 8 + (r & 7u);
     if (item >= a.n_items) return;                       // padding of the last group (whole workgroup)
     ta_col = tb_arg + (int)(r >> 3);                     // the diagonal tile first
+  }
+  if (MODE == 0 && a.only_guarded) {          // re-solve pass behind the Levinson-Whittle recursion: flagged windows only
+    if (*yw_guard_ptr(a.ws, item, p, TILE) == 0) return;
   }
   const YwPtrs q = yw_ptrs<MP>(a, item);
   if (threadIdx.x == 0) s_info = 0;
@@ -499,15 +394,28 @@ static int launch_yw_nt(const YwArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int launch_yw(const YwArgs& a, int m_pad, hipStream_t st) {
+int launch_yw(const YwArgs& a_in, int m_pad, hipStream_t st) {
+  YwArgs a = a_in;
+  a.only_guarded = 0;
   if (a.n_items == 0) return 0;
+  // No LDL^T form asked for: the block Levinson-Whittle recursion (half the tile products, a quarter of the state), then
+  // the one-launch LDL^T over the windows whose tile inverses tripped the conditioning guard (normally none: every other
+  // workgroup of that launch reads one int and exits).
+  const long long form = tuning(4 /* HMV_TUNE_YW_FORM */);
+  if (a.tiled < 0 && form != 1) {
+    int rc = launch_yw_lwr(a, m_pad, st);
+    if (rc) return rc;
+    a.only_guarded = 1;
+    a.tiled = 0;
+  }
   // One launch per batch is the low-latency form (small batches, small tiles).  At 64 channels and hundreds of
   // windows both forms are bound by the same HBM traffic (~14 MB of tile operands per window, far more than any
   // cache holds for a resident batch) and the launch chain, whose every launch streams with the whole chip, is the
   // faster one: 2.0 ms against 2.26 ms for 599 windows (profiles/r02_ab_notes.md).
   const bool one_launch = a.tiled == 0 || (a.tiled < 0 && !(m_pad == 64 && a.n_items >= 128));
   if (one_launch) {
-    if (const hipError_t e = hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st)) return (int)e;
+    if (!a.only_guarded)
+      if (const hipError_t e = hipMemsetAsync(a.info, 0, sizeof(int) * a.n_items, st)) return (int)e;
     const dim3 grid((unsigned)a.n_items), block(256);
     const bool vq = (a.Vq_logdet != nullptr);
     switch (m_pad) {

@@ -543,6 +543,65 @@ def test_yule_walker_one_launch_equals_tiled_launch_chain(m, n, p):
     assert_parity(a1[5, :m, :m].cpu().numpy(), aro, 1e-8); assert_parity(v1[5, :m, :m].cpu().numpy(), Vo, 1e-8)
 
 
+@pytest.mark.parametrize("m,n,p", [(64, 1000, 8), (64, 700, 3), (50, 900, 5), (33, 500, 2), (19, 400, 6), (16, 300, 1),
+                                   (5, 200, 9), (64, 1200, 16)])
+def test_levinson_whittle_solver_against_the_block_ldlt_and_the_oracle(m, n, p):
+    """K2's default form -- the block Levinson-Whittle recursion on the p + 1 lag blocks (csrc/yw_lwr.hip) -- against the
+    block LDL^T of the augmented matrix (csrc/yw_solve.hip) and against the oracle's dense solve: coefficients, residual
+    covariance and the log determinants of every lower order (the criterion's terms, here straight from the recursion's
+    own forward error covariances) agree to ~1e-12 on well-conditioned windows; no window trips the guard."""
+    from hyperscanning_signal_analysis_amd import _lib
+    eng = default_engine()
+    W = 29
+    x = synthetic_var_dyad(41, m=m, p=min(p, 4), T=n + 10 * (W - 1), burn=300)
+    xd = eng.to_device(x[None])
+    rec = torch.zeros(W, dtype=torch.int64, device=eng.device)
+    st = 10 * torch.arange(W, dtype=torch.int64, device=eng.device)
+    R = eng.lagcov(xd, rec, st, n, p)
+    a0, v0, l0, i0 = eng.yw_solve(R, m, True)                                   # default: the recursion
+    a1, v1, l1, i1 = eng.yw_solve(R, m, True, flags=_lib.FLAG_YW_ONE_LAUNCH)      # block LDL^T
+    a2, v2, _, i2 = eng.yw_solve(R, m, False)
+    torch.cuda.synchronize()
+    assert not bool(i0.any()) and not bool(i1.any()) and not bool(i2.any())
+    assert torch.equal(a0, a2) and torch.equal(v0, v2)                          # with / without the log determinants
+    assert not torch.equal(a0, a1)                                              # really two different algorithms
+    for got, want in ((a0, a1), (v0, v1), (l0, l1)):
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-10
+    aro, Vo = O.ar_coeff(x[:, 50:50 + n], p)
+    assert_parity(a0[5, :m, :m].cpu().numpy(), aro, 1e-9); assert_parity(v0[5, :m, :m].cpu().numpy(), Vo, 1e-9)
+
+
+def test_levinson_whittle_guard_re_solves_ill_conditioned_windows(golden):
+    """Levinson-type recursions lose accuracy with the conditioning of the error covariances they invert.  Every tile
+    inverse reports its extreme pivots; a window in which their ratio falls below 1e-7 is re-solved by the block LDL^T in
+    the same call.  The nearly collinear fixtures (cond 2e9, 2e13) come out with the LDL^T's bits, the cond-2e5 fixture and
+    an ordinary window with the recursion's; the exactly rank-deficient window is still reported singular."""
+    from hyperscanning_signal_analysis_amd import _lib
+    g = golden("g6_errors.npz")
+    eng = default_engine()
+    m, n = g["nc0_x"].shape
+    p = g["nc0_ar"].shape[2]
+    ordinary = synthetic_var_dyad(43, m=m, p=min(p, 4), T=n, burn=300)
+    batch = np.stack([g["nc0_x"], ordinary, g["nc1_x"], g["nc2_x"], g["xs"]])
+    xd = eng.to_device(batch)
+    W = batch.shape[0]
+    rec = torch.arange(W, dtype=torch.int64, device=eng.device)
+    st = torch.zeros(W, dtype=torch.int64, device=eng.device)
+    R = eng.lagcov(xd, rec, st, n, p)
+    a0, v0, _, i0 = eng.yw_solve(R, m)
+    a1, v1, _, i1 = eng.yw_solve(R, m, flags=_lib.FLAG_YW_ONE_LAUNCH)
+    torch.cuda.synchronize()
+    for k in (2, 3):                       # guarded: the LDL^T's result, bit for bit
+        assert torch.equal(a0[k], a1[k]) and torch.equal(v0[k], v1[k]) and int(i0[k]) == int(i1[k]) == 0
+    for k in (0, 1):                       # not guarded: the recursion's own result, close to the LDL^T's
+        assert not torch.equal(a0[k], a1[k]) and int(i0[k]) == 0
+    assert int(i0[4]) != 0 and int(i1[4]) != 0          # rank deficient: singular either way
+    cond0, eps = float(g["nc0_cond"]), 2.2e-16
+    assert rel(a0[0, :m, :m].cpu().numpy(), g["nc0_ar"]) < 1e2 * cond0 * eps
+    for k, name in ((2, "nc1"), (3, "nc2")):
+        assert rel(a0[k, :m, :m].cpu().numpy(), g[name + "_ar"]) < 1e2 * float(g[name + "_cond"]) * eps
+
+
 @pytest.mark.parametrize("m,n,hop,p,T,first", [(64, 1000, 500, 8, 6000, 0), (64, 1000, 250, 8, 4250, 250), (19, 90, 45, 3, 1000, 10),
                                              (5, 66, 33, 2, 400, 4), (33, 512, 64, 6, 2048, 0), (48, 300, 100, 4, 1500, 200)])
 def test_lag_covariances_from_shared_hop_blocks(m, n, hop, p, T, first):
