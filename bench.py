@@ -11,6 +11,13 @@ last windows of the batch) over those windows, input already resident in HBM, ou
 `--gpus 8 --dyads-per-gpu 8` is BASELINE.json configs[2] ("C3": 64 dyads, dyad-sharded across 8 GPUs).
 N > 1: weak scaling, rank r processes dyads r*D .. r*D+D-1 (no data-path collective); after the K timed steps
 ONE RCCL gather of the band-integrated ffDTF to rank 0 (inside the timed region).
+`--shard windows` is the strong-scaling mode (secondary partitioning: C2 at 2 / 4 / 8 GPUs): ONE dyad,
+rank r uploads only the samples of its window range (read-only halo of one window) and computes those windows; same
+gather; `"scaling": "strong"`.
+Side measurements on the same line (N = 1, after the headline's timed region; `--no-side` skips them):
+`end_to_end` -- recordings streamed from pinned host memory through `Engine.stream_dyads` (H2D of dyad d+1 and D2H of
+the band-integrated result of dyad d-1 under the compute of dyad d), windows/s including PCIe both ways;
+`with_spectra` -- ffDTF and the spectra S = H V H^T of every window from one fit.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -116,6 +123,12 @@ def main():
     ap.add_argument("--with-spectra", action="store_true",
                     help="side measurement: ffDTF AND multivariate spectra S = H V H^T of every window from one fit "
                          "(what the reference's orchestrators always compute together); reported as `with_spectra`")
+    ap.add_argument("--shard", default="dyads", choices=("dyads", "windows"),
+                    help="N > 1: dyads = weak scaling (one or D dyads per rank); windows = strong scaling (ONE dyad, every "
+                         "rank a window range of it)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side measurements (end_to_end, with_spectra)")
+    ap.add_argument("--stream-dyads", type=int, default=0,
+                    help="recordings streamed in the end_to_end side measurement (default: max(4, dyads per GPU))")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code path "
                          "with several ranks on ONE GPU)")
@@ -142,22 +155,33 @@ def main():
     positions, w = window_positions(T, n_windows, w)
     freqs = northstar_freqs(F)
     D = max(1, args.dyads_per_gpu)
-
-    # weak scaling: dyad index = rank * D + d
-    x_hosts = [synthetic_var_dyad(rank * D + d, m=m, p=p, T=T, fs=fs) for d in range(D)]
+    strong = (args.shard == "windows")
     eng = Engine(device=dev, max_workspace_bytes=64 << 30)
-    x = eng.to_device(np.stack(x_hosts))                                # (D, 64, T) resident in HBM
-    item_rec, item_start = window_items(D, positions, dev)
     fdev = eng.to_device(freqs)
-    n_items = D * n_windows
+    if strong:
+        # strong scaling: ONE dyad (index 0, the same on every rank); this rank uploads only its window range's samples
+        assert D == 1, "--shard windows is one dyad"
+        x_hosts = [synthetic_var_dyad(0, m=m, p=p, T=T, fs=fs)]
+        s_lo, s_hi, my_pos, (w_lo, w_hi) = hdist.shard_window_items(positions, w, world, rank)
+        x = eng.to_device(np.ascontiguousarray(x_hosts[0][None, :, s_lo:s_hi]))
+        item_rec, item_start = window_items(1, my_pos, dev)
+        n_items = int(w_hi - w_lo)
+        all_positions, positions = positions, my_pos
+    else:
+        # weak scaling: dyad index = rank * D + d
+        x_hosts = [synthetic_var_dyad(rank * D + d, m=m, p=p, T=T, fs=fs) for d in range(D)]
+        x = eng.to_device(np.stack(x_hosts))                            # (D, 64, T) resident in HBM
+        item_rec, item_start = window_items(D, positions, dev)
+        n_items = D * n_windows
+        all_positions = positions
     out = eng.empty(n_items, m, m, F)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:                                                     # create the hipEvent_t handles
         a.record(); b.record()
     torch.cuda.synchronize()
 
-    chunk = n_windows                       # one chunk per dyad: K1, K3 are launched once per dyad and step
-    k3_windows = n_windows                  # windows of the K3 launch the events bracket (the last chunk's)
+    chunk = n_items if strong else n_windows   # one chunk per dyad: K1, K3 are launched once per dyad and step
+    k3_windows = chunk                         # windows of the K3 launch the events bracket (the last chunk's)
     two_streams = not args.single_stream
     flags = (hlib.FLAG_UNFUSED_NORM if args.unfused_norm else 0) | (hlib.FLAG_YW_ONE_LAUNCH if args.yw_one_launch else 0)
 
@@ -185,6 +209,10 @@ def main():
         step((ev[k][0].cuda_event, ev[k][1].cuda_event))
     if world > 1:                                                       # the single gather at the end
         bands = hdist.band_integrate(out, freqs, engine=eng)
+        if strong:                                                      # window ranges differ by one: equal shapes for the gather
+            n_max = -(-n_windows // world)
+            if bands.shape[0] < n_max:
+                bands = torch.cat([bands, bands.new_zeros(n_max - bands.shape[0], *bands.shape[1:])])
         gathered = hdist.gather_to_root(bands.cpu() if rehearsal else bands, dst=0)
     torch.cuda.synchronize()
     barrier()
@@ -199,7 +227,9 @@ def main():
 
     # ---- after the timed region: one checked step (diagnostic kernel variants may skip it)
     checks = {}
-    if not os.environ.get("HYPERMVAR_BENCH_NOCHECK"):
+    if os.environ.get("HYPERMVAR_BENCH_NOCHECK"):
+        checks = {"skipped": True}
+    else:
         _, _, _, (info_yw, info_tf) = step(check=True)                 # raises on any singular window
         checks["info_all_zero"] = not (bool(info_yw.any()) or bool(info_tf.any()))
         rowsum_err = float((out.sum(dim=(2, 3)) - 1.0).abs().max().item())
@@ -213,14 +243,38 @@ def main():
         del other
         if rank == 0:
             from oracle import mvar_oracle as O                          # checker only
-            kw = n_windows // 2
-            ref = O.full_freq_dtf(x_hosts[0][:, positions[kw]:positions[kw] + w], freqs, fs, p)
+            kw = n_items // 2 if strong else n_windows // 2
+            a0 = int(all_positions[kw + (w_lo if strong else 0)])
+            ref = O.full_freq_dtf(x_hosts[0][:, a0:a0 + w], freqs, fs, p)
             got = out[kw].cpu().numpy()
             checks["oracle_window_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
             assert checks["oracle_window_rel_err"] < 1e-9
 
+    # ---- side measurement: recordings streamed from (pinned) host memory, PCIe both ways inside the clock
+    e2e_res = None
+    side = (world == 1 and not strong and not args.no_side)
+    if side:
+        E = args.stream_dyads or max(4, D)
+        feed_src = [torch.from_numpy(xh).pin_memory() for xh in x_hosts]          # what a loader would hand over
+        feed = [feed_src[d % len(feed_src)] for d in range(E)]
+        eng.stream_dyads(feed[:2], w, positions, p, fdev, fs)                      # warm-up: buffers, streams
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        red = eng.stream_dyads(feed, w, positions, p, fdev, fs)
+        torch.cuda.synchronize()
+        te = time.perf_counter() - te0
+        ref_b = hdist.band_integrate(out[:n_windows], freqs, engine=eng).cpu().numpy()
+        e2e_res = {"windows_per_s": E * n_windows / te, "dyads_streamed": E, "ms_per_dyad": te / E * 1e3,
+                   "fraction_of_resident_rate": (E * n_windows / te) / (world * n_items * args.steps / dt),
+                   "h2d_bytes_per_dyad": int(x_hosts[0].nbytes), "d2h_bytes_per_dyad": int(red[0].nbytes),
+                   "what": "Engine.stream_dyads: pinned host recordings -> H2D on a copy stream under the compute of the "
+                           "previous dyad -> band-integrated ffDTF (windows, 64, 64, 5) D2H on a third stream",
+                   "first_dyad_equals_resident_result_bitwise": bool(np.array_equal(red[0], ref_b))}
+        assert e2e_res["first_dyad_equals_resident_result_bitwise"], "streamed and resident results differ"
+        del feed, feed_src, red
+
     spectra_res = None
-    if args.with_spectra:                    # ffDTF + spectra of dyad 0 from one fit, after the headline measurement
+    if args.with_spectra or side:            # ffDTF + spectra of dyad 0 from one fit, after the headline measurement
         nsp = n_windows
         S_out = eng.empty(nsp, m, m, F, 2)
         ff_sp = eng.empty(nsp, m, m, F)
@@ -231,10 +285,10 @@ def main():
         sp_step()
         torch.cuda.synchronize()
         ts0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(4):
             sp_step()
         torch.cuda.synchronize()
-        ts = (time.perf_counter() - ts0) / 3
+        ts = (time.perf_counter() - ts0) / 4
         spectra_res = {"windows_per_s": nsp / ts, "ms_per_window": ts / nsp * 1e3, "windows": nsp,
                        # (bitwise when K1 is the same: this path sums every window from its own samples)
                        "ffdtf_max_rel_diff_to_headline_path": float((ff_sp - out[:nsp]).abs().max() / out[:nsp].abs().max()),
@@ -247,48 +301,64 @@ def main():
         windows_total = world * n_items * args.steps
         value = windows_total / dt
         achieved = FLOP_K3_WINDOW * k3_windows / (k3_ms * 1e-3) / 1e12
+        k3_form = int(eng.lib.hmv_get_tuning(hlib.TUNE_K3_FORM))
+        k3_name = "tf_inv_kernel<4, false>" if k3_form == 1 else "tf_inv64_asm_kernel"
+        # HBM bytes per K3 launch from the PMC passes of tools/profile_round.sh: valid only for the kernel it was measured
+        # on (the file names it) -- a stale figure is dropped, not reported
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "k3_traffic.json")
         if os.path.exists(pmc):
             try:
                 tj = json.load(open(pmc))
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/k3_traffic.json (%s)" % tj.get("round", "r01")
+                if k3_name.split("<")[0] in tj.get("kernel", "") and not args.unfused_norm:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/k3_traffic.json (%s, %s)" % (tj.get("round", "?"), tj.get("kernel", "?"))
+                else:
+                    traffic_src = "none: profiles/k3_traffic.json was measured on '%s'" % tj.get("kernel", "?")
             except Exception:
                 traffic = None
         res = {
             "metric": "MVAR+ffDTF windows/sec, 2x32-ch dyad p=8, 256 freqs",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C%d: %d dyad(s)/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
+            "config": {"workload": ("C2 strong scaling: ONE dyad, window ranges over %d GPU(s), 2x32 ch @500 Hz, %g min, 2 s "
+                                    "windows 50%% overlap (%d windows), MVAR p=8, 256 freqs 0.5-128 Hz"
+                                    % (world, args.minutes, n_windows)) if strong else
+                                   "C%d: %d dyad(s)/GPU, 2x32 ch @500 Hz, %g min, 2 s windows 50%% overlap "
                                    "(%d windows per dyad), MVAR p=8, 256 freqs 0.5-128 Hz"
                                    % (2 if D == 1 else 3, D, args.minutes, n_windows),
                        "windows_per_step_per_gpu": n_items, "dyads_per_gpu": D,
                        "k1": "every window from its own samples" if grid is None else
                              "hop blocks summed once, shared by the overlapping windows (hop %d)" % grid[0],
-                       "k2": "one workgroup per window, one launch" if args.yw_one_launch
-                             else "tile launches on %d stream(s)" % (2 if two_streams else 1),
+                       "k2": "block LDL^T, one workgroup per window, one launch" if args.yw_one_launch
+                             else ("block LDL^T (HYPERMVAR_YW_FORM=1)" if int(eng.lib.hmv_get_tuning(hlib.TUNE_YW_FORM)) == 1
+                                   else "block Levinson-Whittle recursion, one workgroup per window, one launch"),
+                       "pivot_tau": eng.pivot_tau,
                        "normalisation": "separate K4 pass" if args.unfused_norm else "inside K3 (rows of window w by "
                                         "workgroups of window w+lag)",
                        "timed_steps_check_singularity": False,
-                       "parallelism": f"dyad-sharded x{world}",
+                       "parallelism": (f"window-range-sharded x{world}" if strong else f"dyad-sharded x{world}"),
                        "gather": "band-integrated ffDTF to rank 0 (once, timed)" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "tf_inv_kernel<4, false> (K3%s)"
-                                  % ("" if args.unfused_norm else ", incl. the in-kernel ffDTF normalisation"),
+            "roofline": {"bound": "mfma", "kernel": "%s (K3%s)"
+                                  % (k3_name, "" if args.unfused_norm else ", incl. the in-kernel ffDTF normalisation"),
                          "achieved": achieved,
                          "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F64_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src, "k3_ms_per_launch": k3_ms,
                          "flop_per_launch": FLOP_K3_WINDOW * k3_windows, "windows_per_launch": k3_windows},
+            # ALGORITHMIC flops of the direct form (727.4 MFLOP per window); with the shared hop blocks
+            # K1 executes about half of its 73.4 MFLOP, i.e. the work actually done is ~5 % less than this figure counts
             "path_tflops": FLOP_WINDOW * value / world / 1e12,
             "path_frac_of_peak": FLOP_WINDOW * value / world / 1e12 / PEAK_F64_TFLOPS,
+            "path_flops_are": "algorithmic (direct-form K1), not executed",
             "checks_after_timed_region": checks,
         }
         if spectra_res is not None:
             res["with_spectra"] = spectra_res
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(x_hosts[0], positions, w, p, freqs, fs)
-        elif not args.no_cpu_baseline:
-            res["cpu_baseline"] = None
+        if e2e_res is not None:
+            res["end_to_end"] = e2e_res
+        if not args.no_cpu_baseline:           # rank 0's host cores, whatever N is
+            res["cpu_baseline"] = cpu_baseline(x_hosts[0], all_positions, w, p, freqs, fs)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

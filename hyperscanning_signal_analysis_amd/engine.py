@@ -392,6 +392,9 @@ class Engine:
             badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
             if bool(badw.any()):
                 out[badw] = float("nan")
+        elif check == "nan-async":  # the same without a host synchronisation (streamed recordings)
+            badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
+            out.masked_fill_(badw.view(-1, 1, 1, 1), float("nan"))
         elif check:
             self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
             self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
@@ -399,6 +402,96 @@ class Engine:
             return out, ar, V, (info_yw, info_tf)
         return out
 
+
+    # ------------------------------------------------------------------ recordings streamed from the host
+    def stream_dyads(self, dyads, n: int, positions, p: int, freqs, fs: float, bands=None, reduce=None, depth: int = 2,
+                     check="nan", keep_full=None, timeline=None):
+        """The reference's outer loop -- load a recording, compute, save, next (eeg_alpha_ibi_ffdtf.py:661-806) -- as a
+        pipeline: while recording d computes, recording d + 1 crosses PCIe on a copy stream and the reduced result of
+        recording d - 1 goes back on another one.  `dyads`: an iterable of host arrays (m, T) float64 -- NumPy arrays
+        (staged through pinned buffers) or pinned torch tensors (copied as they are).  Every recording gets the windows
+        `positions` (length n).  What leaves the device per recording is `reduce(ffdtf)` -- by default the band-integrated
+        ffDTF (windows, m, m, n_bands) of `bands` (`distributed.DEFAULT_BANDS`): full-resolution ffDTF is 5 GB per
+        10-minute dyad, i.e. >= 80 ms of PCIe against ~10 ms of compute.  `keep_full(d, ffdtf_device)` is called (on the
+        compute stream's timeline) for callers that want to consume the full array on the device.
+        Returns the list of reduced results as NumPy arrays, in order.  Same bits as the resident path: the arithmetic
+        does not know where its input came from (tests/test_gpu_pipeline.py)."""
+        from . import distributed as hdist
+        from .sliding import regular_grid, window_items
+        dev = self.device
+        f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
+        fhost = f.cpu().numpy()
+        lo, hi = hdist.band_bins(fhost, hdist.DEFAULT_BANDS if bands is None else bands)
+        if reduce is None:
+            def reduce(ff):
+                return self.band_sums(ff, lo, hi)
+        pos = np.asarray(positions, dtype=np.int64)
+        item_rec, item_start = window_items(1, pos, dev)
+        grid = regular_grid(pos, n, p)
+        import collections
+        import time
+        comp = torch.cuda.current_stream(dev)
+        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        slots, results, pending = [], [], collections.deque()
+
+        def collect_one():
+            d, k = pending.popleft()
+            slots[k]["d2h"].synchronize()
+            results.append(slots[k]["out_pin"].numpy().copy())
+            if timeline is not None:
+                timeline.append(("collected", d, time.perf_counter()))
+
+        for d, arr in enumerate(dyads):
+            k = d % depth
+            while pending and pending[0][0] <= d - depth:      # slot k's previous recording: result on the host first
+                collect_one()
+            pinned_in = isinstance(arr, torch.Tensor) and arr.is_pinned()
+            host = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+            m, T = host.shape
+            if len(slots) <= k:
+                slots.append({"x": self.empty(1, m, T), "ff": self.empty(len(pos), m, m, int(f.numel())), "in_pin": None,
+                              "h2d": torch.cuda.Event(), "done": torch.cuda.Event(), "d2h": torch.cuda.Event(),
+                              "red": None, "out_pin": None})
+            sl = slots[k]
+            if tuple(sl["x"].shape[1:]) != (m, T):
+                raise ValueError("stream_dyads: every recording must have the same shape")
+            if pinned_in:
+                src = host
+            else:
+                if sl["in_pin"] is None:
+                    sl["in_pin"] = torch.empty(m, T, dtype=torch.float64).pin_memory()
+                elif d >= depth:
+                    sl["h2d"].synchronize()                    # the copy out of this staging buffer has finished
+                sl["in_pin"].copy_(host)                       # host memcpy, under the GPU's work on earlier recordings
+                src = sl["in_pin"]
+            with torch.cuda.stream(s_in):
+                if d >= depth:
+                    s_in.wait_event(sl["done"])                # the kernels that read x[k] have finished
+                sl["x"][0].copy_(src, non_blocking=True)
+                sl["h2d"].record(s_in)
+            comp.wait_event(sl["h2d"])
+            ff = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["ff"],
+                                    check="nan-async" if check == "nan" else False, grid=grid)
+            if keep_full is not None:
+                keep_full(d, ff)
+            red = reduce(ff)
+            if sl["red"] is None or sl["red"].shape != red.shape:
+                sl["red"] = torch.empty_like(red)
+                sl["out_pin"] = torch.empty(red.shape, dtype=red.dtype).pin_memory()
+            elif d >= depth:
+                comp.wait_event(sl["d2h"])                     # (already collected on the host: a formality)
+            sl["red"].copy_(red)
+            sl["done"].record(comp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(sl["done"])
+                sl["out_pin"].copy_(sl["red"], non_blocking=True)
+                sl["d2h"].record(s_out)
+            pending.append((d, k))
+            if timeline is not None:
+                timeline.append(("queued", d, time.perf_counter()))
+        while pending:
+            collect_one()
+        return results
 
     # ------------------------------------------------------------------ ffDTF + spectra from ONE fit
     def sliding_ffdtf_spectra(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,

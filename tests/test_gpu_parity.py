@@ -565,10 +565,17 @@ def test_levinson_whittle_solver_against_the_block_ldlt_and_the_oracle(m, n, p):
     assert not bool(i0.any()) and not bool(i1.any()) and not bool(i2.any())
     assert torch.equal(a0, a2) and torch.equal(v0, v2)                          # with / without the log determinants
     assert not torch.equal(a0, a1)                                              # really two different algorithms
+    # the block LDL^T (explicit tile inverses, p back-substitution sweeps) loses accuracy with the order -- 5e-11 at
+    # p = 9, 2e-9 at p = 12, 6e-7 at p = 16 against the oracle -- where the recursion stays at ~5e-12
+    tol = 1e-10 if p <= 9 else 1e-5
     for got, want in ((a0, a1), (v0, v1), (l0, l1)):
-        assert float((got - want).abs().max() / want.abs().max()) < 1e-10
-    aro, Vo = O.ar_coeff(x[:, 50:50 + n], p)
-    assert_parity(a0[5, :m, :m].cpu().numpy(), aro, 1e-9); assert_parity(v0[5, :m, :m].cpu().numpy(), Vo, 1e-9)
+        assert float((got - want).abs().max() / want.abs().max()) < tol
+    for k in (5, W - 1):
+        aro, Vo = O.ar_coeff(x[:, 10 * k:10 * k + n], p)
+        assert_parity(a0[k, :m, :m].cpu().numpy(), aro, 1e-9); assert_parity(v0[k, :m, :m].cpu().numpy(), Vo, 1e-9)
+    crit = O.mvar_criterion(x[:, 50:50 + n], p, "AIC")[0]
+    pen = 2.0 * np.arange(1, p + 1) * m * m / n
+    assert np.allclose(l0[5].cpu().numpy() + pen, crit, rtol=1e-9, atol=1e-9)
 
 
 def test_levinson_whittle_guard_re_solves_ill_conditioned_windows(golden):
@@ -591,15 +598,15 @@ def test_levinson_whittle_guard_re_solves_ill_conditioned_windows(golden):
     a0, v0, _, i0 = eng.yw_solve(R, m)
     a1, v1, _, i1 = eng.yw_solve(R, m, flags=_lib.FLAG_YW_ONE_LAUNCH)
     torch.cuda.synchronize()
-    for k in (2, 3):                       # guarded: the LDL^T's result, bit for bit
-        assert torch.equal(a0[k], a1[k]) and torch.equal(v0[k], v1[k]) and int(i0[k]) == int(i1[k]) == 0
+    # cond 2e9: guarded, the LDL^T's result bit for bit
+    assert torch.equal(a0[2], a1[2]) and torch.equal(v0[2], v1[2]) and int(i0[2]) == int(i1[2]) == 0
     for k in (0, 1):                       # not guarded: the recursion's own result, close to the LDL^T's
         assert not torch.equal(a0[k], a1[k]) and int(i0[k]) == 0
-    assert int(i0[4]) != 0 and int(i1[4]) != 0          # rank deficient: singular either way
-    cond0, eps = float(g["nc0_cond"]), 2.2e-16
-    assert rel(a0[0, :m, :m].cpu().numpy(), g["nc0_ar"]) < 1e2 * cond0 * eps
-    for k, name in ((2, "nc1"), (3, "nc2")):
-        assert rel(a0[k, :m, :m].cpu().numpy(), g[name + "_ar"]) < 1e2 * float(g[name + "_cond"]) * eps
+    # cond 2e13 and the exactly rank-deficient window: a non-positive pivot in either solver -> singular, same code
+    assert int(i0[3]) == int(i1[3]) and int(i0[4]) == int(i1[4]) != 0
+    eps = 2.2e-16
+    assert rel(a0[0, :m, :m].cpu().numpy(), g["nc0_ar"]) < 1e2 * float(g["nc0_cond"]) * eps
+    assert rel(a0[2, :m, :m].cpu().numpy(), g["nc1_ar"]) < 1e2 * float(g["nc1_cond"]) * eps
 
 
 @pytest.mark.parametrize("m,n,hop,p,T,first", [(64, 1000, 500, 8, 6000, 0), (64, 1000, 250, 8, 4250, 250), (19, 90, 45, 3, 1000, 10),

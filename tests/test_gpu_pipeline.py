@@ -112,3 +112,34 @@ def test_compute_ffdtf_on_reference_block(tmp_path, golden):
     assert p_opt == int(g["p_block"])
     assert np.abs(ff - g["ff_block"]).max() <= 1e-9 * np.abs(g["ff_block"]).max()
     assert np.abs(sp - g["sp_block"]).max() <= 1e-9 * np.abs(g["sp_block"]).max()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_streamed_recordings_equal_resident_ones(pinned):
+    """`Engine.stream_dyads` (H2D of recording d + 1 and D2H of recording d - 1 under the compute of recording d, three HIP
+    streams, two buffer slots reused round robin) returns what the resident path computes, bit for bit, for every
+    recording -- from NumPy arrays (staged through pinned buffers) and from pinned tensors (copied as they are); a
+    recording with a dead channel comes back NaN-filled in its windows without stopping the stream."""
+    from hyperscanning_signal_analysis_amd import distributed as hdist
+    from hyperscanning_signal_analysis_amd.engine import default_engine
+    from hyperscanning_signal_analysis_amd.sliding import regular_grid, window_items, window_positions
+    from hyperscanning_signal_analysis_amd.synthetic import synthetic_var_dyad
+    eng = default_engine()
+    m, T, n, p = 64, 9000, 1000, 8
+    freqs = 0.5 * np.arange(1, 65)
+    pos, n = window_positions(T, 2 * T // n - 1, n)
+    recs = [synthetic_var_dyad(50 + d, m=m, p=4, T=T, burn=300) for d in range(5)]
+    recs[3] = recs[3].copy()
+    recs[3][7] = 0.0                                               # a dead channel: singular fits
+    feed = [torch.from_numpy(r).pin_memory() for r in recs] if pinned else recs
+    tl = []
+    got = eng.stream_dyads(feed, n, pos, p, freqs, 500.0, depth=2, timeline=tl)
+    assert len(got) == 5 and [e[1] for e in tl if e[0] == "collected"] == [0, 1, 2, 3, 4]
+    lo, hi = hdist.band_bins(freqs)
+    rec_i, st_i = window_items(1, pos, eng.device)
+    for d, r in enumerate(recs):
+        ff = eng.sliding_ffdtf(eng.to_device(r[None]), rec_i, st_i, n, p, freqs, 500.0, check="nan", grid=regular_grid(pos, n, p))
+        want = eng.band_sums(ff, lo, hi).cpu().numpy()
+        assert got[d].shape == want.shape == (len(pos), m, m, len(hdist.DEFAULT_BANDS))
+        assert np.array_equal(got[d], want, equal_nan=True), d
+        assert np.isnan(want).all() == (d == 3)
