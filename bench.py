@@ -254,13 +254,15 @@ def main():
     e2e_res = None
     side = (world == 1 and not strong and not args.no_side)
     if side:
-        E = args.stream_dyads or max(4, D)
+        E = args.stream_dyads or max(8, D)
         feed_src = [torch.from_numpy(xh).pin_memory() for xh in x_hosts]          # what a loader would hand over
         feed = [feed_src[d % len(feed_src)] for d in range(E)]
-        eng.stream_dyads(feed[:2], w, positions, p, fdev, fs)                      # warm-up: buffers, streams
+        nb = len(hdist.DEFAULT_BANDS)
+        host_out = torch.empty(E, n_windows, m, m, nb, dtype=torch.float64).pin_memory()   # the caller's result buffer
+        eng.stream_dyads(feed[:2], w, positions, p, fdev, fs, out=host_out)        # warm-up: buffers, streams
         torch.cuda.synchronize()
         te0 = time.perf_counter()
-        red = eng.stream_dyads(feed, w, positions, p, fdev, fs)
+        red = eng.stream_dyads(feed, w, positions, p, fdev, fs, out=host_out)
         torch.cuda.synchronize()
         te = time.perf_counter() - te0
         ref_b = hdist.band_integrate(out[:n_windows], freqs, engine=eng).cpu().numpy()
@@ -271,7 +273,7 @@ def main():
                            "previous dyad -> band-integrated ffDTF (windows, 64, 64, 5) D2H on a third stream",
                    "first_dyad_equals_resident_result_bitwise": bool(np.array_equal(red[0], ref_b))}
         assert e2e_res["first_dyad_equals_resident_result_bitwise"], "streamed and resident results differ"
-        del feed, feed_src, red
+        del feed, feed_src, red, host_out
 
     spectra_res = None
     if args.with_spectra or side:            # ffDTF + spectra of dyad 0 from one fit, after the headline measurement

@@ -35,6 +35,7 @@ SIGNATURES = {
                                    c_void_p]),
     "hmv_transpose_c128": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hmv_spectra_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "hmv_spectra_mmf_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hmv_pack_c128": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hmv_cinv_c128": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
     "hmv_partial_coherence_c128": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -181,7 +181,16 @@ int hmv_spectra_f64(const double* H, const double* V, double* Sout, int64_t n_it
   if (mp < 0) return fail(-1, "hmv_spectra_f64: channel count must be in 1..64");
   if (!H || !V || !Sout) return fail(-4, "hmv_spectra_f64: null pointer");
   hmv::SpecArgs a;
-  a.H = H; a.V = V; a.S = Sout; a.n_items = n_items; a.F = F;
+  a.H = H; a.V = V; a.S = Sout; a.S_mmf = nullptr; a.n_items = n_items; a.F = F; a.m = m;
+  return hmv::launch_spectra(a, mp, S(stream));
+}
+
+int hmv_spectra_mmf_f64(const double* H, const double* V, double* Sout, int64_t n_items, int m, int F, void* stream) {
+  const int mp = pad_of(m);
+  if (mp < 0) return fail(-1, "hmv_spectra_mmf_f64: channel count must be in 1..64");
+  if (!H || !V || !Sout) return fail(-4, "hmv_spectra_mmf_f64: null pointer");
+  hmv::SpecArgs a;
+  a.H = H; a.V = V; a.S = nullptr; a.S_mmf = Sout; a.n_items = n_items; a.F = F; a.m = m;
   return hmv::launch_spectra(a, mp, S(stream));
 }
 

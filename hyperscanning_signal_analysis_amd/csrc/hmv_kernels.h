@@ -111,9 +111,10 @@ int launch_transpose_c128(const double* in, double* out, long long n_items, int 
 struct SpecArgs {
   const double* H;          // complex [n_items][F][MP][MP]
   const double* V;          // [n_items][MP][MP]
-  double* S;                // complex [n_items][F][MP][MP]
+  double* S;                // complex [n_items][F][MP][MP] (kernel-natural), or
+  double* S_mmf;            // complex [n_items][m][m][F], the reference's array layout, written by the kernel itself
   long long n_items;
-  int F;
+  int F, m;
 };
 int launch_spectra(const SpecArgs& a, int m_pad, hipStream_t st);
 

@@ -27,8 +27,16 @@ __global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
   constexpr int NVV = (MP * KQ / 2 + 255) / 256;     // 16-byte loads of a V quarter per thread
   __shared__ __attribute__((aligned(16))) double A0[MP * SQ], A1[MP * SQ], B0[MP * SQ], B1[MP * SQ];
   const int wv = uni(threadIdx.x >> 6);
-  const long long gw = blockIdx.x;                 // item * F + f
+  long long gw = blockIdx.x;                       // item * F + f
   const long long item = gw / a.F;
+  if (a.S_mmf && a.F % 64 == 0) {
+    // Output straight into the reference's (m, m, F) layout: one workgroup owns ONE frequency, so its 4096 elements are
+    // 16 bytes each, F * 16 bytes apart -- eight consecutive frequencies make one 128-byte line.  Blocks b and b + 8 share
+    // an XCD (and its L2) and are dispatched back to back: the map below gives them consecutive frequencies, so the
+    // eight partial writes of a line meet in ONE L2 instead of in eight.
+    const int r = (int)(gw - item * a.F), c = r & 7, b8 = (r >> 3) & 7, a64 = r >> 6;
+    gw = item * a.F + (64 * a64 + 8 * c + b8);
+  }
   const f64x2* H = reinterpret_cast<const f64x2*>(a.H) + (size_t)gw * TILE;
   const double* V = a.V + (size_t)item * TILE;
   // thread coordinates re-derived from an opaque lane id per helper (keeps the offsets out of long live ranges)
@@ -153,8 +161,20 @@ __global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
     gemm_q(si, A0, B1, false);                     // Tr Hi^T
     gemm_q(si, A1, B0, false);                     // + Ti Hr^T
   }
-  double2* So = reinterpret_cast<double2*>(a.S) + (size_t)gw * TILE;
   const int l = lane(), i = l >> 4, cc = l & 15;
+  if (a.S_mmf) {
+    const int m = a.m, f = (int)(gw - item * a.F);
+    double2* So = reinterpret_cast<double2*>(a.S_mmf) + (size_t)item * m * m * a.F + f;
+#pragma unroll
+    for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) {
+        const int row = 4 * (wv * NT + ii) + i, col = 16 * J + cc;
+        if (row < m && col < m) So[((size_t)row * m + col) * a.F] = make_double2(sr[ii][J], si[ii][J]);
+      }
+    return;
+  }
+  double2* So = reinterpret_cast<double2*>(a.S) + (size_t)gw * TILE;
 #pragma unroll
   for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll

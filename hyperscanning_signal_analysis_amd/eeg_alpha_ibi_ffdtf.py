@@ -13,6 +13,10 @@ Extra, optional constructor arguments (defaults keep the drop-in behaviour):
              reference's NetCDF files with xarray (imported lazily: xarray is not needed to import this
              module or to run the numerics).
     engine   a `hyperscanning_signal_analysis_amd.engine.Engine` (default: the process-wide one).
+    batch_items  how many dyad x film items are pre-processed on the host before their MVAR work goes to the GPU as ONE
+             batch (every window and every global block of all of them: one lag-covariance, one Yule-Walker, one
+             transfer-function launch per block shape and model order, the AIC order selection included).  Default 256;
+             1 = one dyad x film at a time, as the reference loops.  Results and files do not depend on it (bit for bit).
 """
 from __future__ import annotations
 
@@ -35,7 +39,7 @@ class EEG_IBI_FFDTF_Pipeline:
                  fs_downsampled: float = 8.0, n_windows: int = 3, window_size: int = None, ar_p: int = 5,
                  plot_global_enabled: bool = True, save_global_enabled: bool = True,
                  plot_windowed_enabled: bool = True, save_windowed_enabled: bool = True,
-                 loader=None, engine=None):
+                 loader=None, engine=None, batch_items: int = 256):
         self.cleaned_signals_folder = Path(cleaned_signals_folder)
         self.output_ffDTF_folder = Path(output_ffDTF_folder)
         self.target_events = target_events
@@ -57,6 +61,7 @@ class EEG_IBI_FFDTF_Pipeline:
         self.save_windowed_enabled = save_windowed_enabled
         self._loader = loader
         self._engine = engine
+        self.batch_items = max(1, int(batch_items))
         self.eeg_files = []
         self.ibi_files = []
         self.dyads_to_process = []
@@ -197,30 +202,80 @@ class EEG_IBI_FFDTF_Pipeline:
             self._figure(dyad, spectra, ff_dtf, freqs, chan_names, plot, save_plot, save_path, fig_name)
         return ff_dtf, spectra, p_opt
 
-    def _compute_ffDTF_batch(self, windows, fs, max_model_order=20, crit_type="AIC"):
-        """All windows of one dyad x film in a single GPU batch when they share one model order."""
-        freqs = self._freqs()
-        orders = [self._order_for(w, max_model_order, crit_type) for w in windows]
-        same = len(set(orders)) == 1 and len({w.shape for w in windows}) == 1
-        if not same:
-            out = [mtmvar.mvar_analysis(w, freqs, fs, p, want=("ffdtf", "spectra"), engine=self._engine)
-                   for w, p in zip(windows, orders)]
-            return [o["ffdtf"] for o in out], [o["spectra"] for o in out], orders
-        from .engine import default_engine
+    def _orders_for_blocks(self, blocks, max_model_order=20, crit_type="AIC"):
+        """Model order of every block: the fixed `ar_p`, or the criterion's argmin -- for ALL blocks of one shape from one
+        batched fit at `max_model_order` (the recursion's error covariances of every lower order: K2's `vq_logdet`)
+        instead of one `mvar_criterion` call per block (ref :585-589, 726-728; mtmvar.py:551-601)."""
+        if self.ar_p is not None:
+            return [self.ar_p] * len(blocks)
+        _, _, popt = self._criterion_for_blocks(blocks, max_model_order, crit_type)
+        return popt
+
+    def _criterion_for_blocks(self, blocks, max_model_order=20, crit_type="AIC"):
+        """(crit curves, order range, argmin order) per block, batched by block shape; same numbers as
+        `mtmvar.mvar_criterion` block by block."""
         import torch
+        from .engine import default_engine
+        if crit_type not in ("AIC", "HQ", "SC"):
+            raise ValueError("Invalid criterion type. Choose from 'AIC', 'HQ', 'SC'.")
         eng = self._engine or default_engine()
-        x = eng.to_device(np.stack(windows))                       # (n_win, m, n): every window its own "recording"
-        n_win, m, n = x.shape
-        rec = torch.arange(n_win, dtype=torch.int64, device=eng.device)
-        start = torch.zeros(n_win, dtype=torch.int64, device=eng.device)
-        R = eng.lagcov(x, rec, start, n, orders[0])
-        ar, V, _, info = eng.yw_solve(R, m)
-        eng.raise_on_info(info, "ar_coeff")
-        t = eng.transfer(ar, m, eng.twiddles(freqs, fs, orders[0]), want_P=True, want_H=True)
-        eng.raise_on_info(t["info"], "transfer")
-        ff = eng.normalise(t["P"], t["rowsum"], m)[0].cpu().numpy()
-        sp = eng.to_mmf_complex(eng.spectra(t["H"], V, m), m).cpu().numpy()
-        return [ff[k] for k in range(n_win)], [sp[k] for k in range(n_win)], orders
+        rng = np.arange(1, max_model_order + 1, dtype=int)
+        crit_all, popt = [None] * len(blocks), [None] * len(blocks)
+        shapes = {}
+        for k, b in enumerate(blocks):
+            shapes.setdefault(np.asarray(b).shape, []).append(k)
+        for (m, n), idx in shapes.items():
+            x = eng.to_device(np.stack([np.asarray(blocks[k], dtype=np.float64) for k in idx]))
+            B = len(idx)
+            rec = torch.arange(B, dtype=torch.int64, device=eng.device)
+            st = torch.zeros(B, dtype=torch.int64, device=eng.device)
+            R = eng.lagcov(x, rec, st, n, int(max_model_order))
+            _, _, logdet, info = eng.yw_solve(R, m, want_logdet=True)
+            eng.raise_on_info(info, "ar_coeff (Yule-Walker solve)")
+            if crit_type == "AIC":
+                pen = 2 * rng * m ** 2 / n
+            elif crit_type == "HQ":
+                pen = 2 * np.log(np.log(n)) * rng * m ** 2 / n
+            else:
+                pen = np.log(n) * rng * m ** 2 / n
+            crit = logdet.cpu().numpy() + pen[None, :]
+            for j, k in enumerate(idx):
+                crit_all[k] = crit[j]
+                popt[k] = int(rng[int(np.argmin(crit[j]))])          # first minimum, like the reference's argmin
+        return crit_all, rng, popt
+
+    def _compute_blocks(self, blocks, orders, fs):
+        """ffDTF and spectra of many (m, n) blocks: every group of equal shape and order is ONE GPU batch (each block its
+        own "recording": K1 -> K2 -> K3 -> K4 / K5).  Returns (ff list, spectra list) in the order of `blocks`."""
+        import torch
+        from .engine import default_engine
+        eng = self._engine or default_engine()
+        freqs = self._freqs()
+        ff_out, sp_out = [None] * len(blocks), [None] * len(blocks)
+        groups = {}
+        for k, (b, p) in enumerate(zip(blocks, orders)):
+            groups.setdefault((np.asarray(b).shape, int(p)), []).append(k)
+        for ((m, n), p), idx in groups.items():
+            x = eng.to_device(np.stack([np.asarray(blocks[k], dtype=np.float64) for k in idx]))
+            B = len(idx)
+            rec = torch.arange(B, dtype=torch.int64, device=eng.device)
+            start = torch.zeros(B, dtype=torch.int64, device=eng.device)
+            R = eng.lagcov(x, rec, start, n, p)
+            ar, V, _, info = eng.yw_solve(R, m)
+            eng.raise_on_info(info, "ar_coeff (Yule-Walker solve)")
+            t = eng.transfer(ar, m, eng.twiddles(freqs, fs, p), want_P=True, want_H=True)
+            eng.raise_on_info(t["info"], "mvar_transfer_function (inverse of A(f))", per_item=len(freqs))
+            ff = eng.normalise(t["P"], t["rowsum"], m)[0].cpu().numpy()
+            sp = eng.to_mmf_complex(eng.spectra(t["H"], V, m), m).cpu().numpy()
+            for j, k in enumerate(idx):
+                ff_out[k], sp_out[k] = ff[j], sp[j]
+        return ff_out, sp_out
+
+    def _compute_ffDTF_batch(self, windows, fs, max_model_order=20, crit_type="AIC"):
+        """All windows of one dyad x film: (ff list, spectra list, orders)."""
+        orders = self._orders_for_blocks(windows, max_model_order, crit_type)
+        ff, sp = self._compute_blocks(windows, orders, fs)
+        return ff, sp, orders
 
     def _figure(self, dyad, spectra, ff_dtf, freqs, chan_names, show, save, save_path, fig_name):
         """m x m grid: |S_ii(f)| on the diagonal, ffDTF_ij(f) (j -> i) elsewhere."""
@@ -270,57 +325,93 @@ class EEG_IBI_FFDTF_Pipeline:
         ibi = self._crop_signal(self._downsample_signal(np.squeeze(ibi), fs_ibi, self.fs_ds), self.fs_ds, 10, 60)
         return faa, ibi
 
+    def _prepare_item(self, dyad, film):
+        """Host part of one dyad x film (ref :669-719): find and load the four files, FAA + IBI -> z-scored 4 x 480 block.
+        Returns None when a file is missing (the reference's [SKIP])."""
+        print(f"--- Processing dyad: {dyad} | Film: {film} ---")
+        paths, missing = {}, []
+        for kind, files in (("EEG", self.eeg_files), ("IBI", self.ibi_files)):
+            for role in ("ch", "cg"):
+                path, ok = self._find_file(files, dyad, film, role)
+                paths[(kind, role)] = path
+                if not ok:
+                    missing.append(f"{kind} ({role})")
+        if missing:
+            order = ["EEG (ch)", "IBI (ch)", "EEG (cg)", "IBI (cg)"]
+            missing.sort(key=order.index)
+            print(f" [SKIP] Missing files: {', '.join(missing)} -> Skipping {film}")
+            return None
+        for kind, role in (("EEG", "ch"), ("IBI", "ch"), ("EEG", "cg"), ("IBI", "cg")):
+            print(f" [OK] Loaded {kind} ({role}) : {paths[(kind, role)].name}")
+        _, eeg_ch, fs_eeg, names, ibi_ch, fs_ibi, _ = self._load_eeg_and_ibi(paths[("EEG", "ch")], paths[("IBI", "ch")], role="Child")
+        _, eeg_cg, fs_eeg, names, ibi_cg, fs_ibi, _ = self._load_eeg_and_ibi(paths[("EEG", "cg")], paths[("IBI", "cg")], role="Care Giver")
+        faa_ch, ibi_ch_c = self._preprocess(eeg_ch, fs_eeg, names, ibi_ch, fs_ibi)
+        faa_cg, ibi_cg_c = self._preprocess(eeg_cg, fs_eeg, names, ibi_cg, fs_ibi)
+        sig = np.vstack([faa_ch, ibi_ch_c, faa_cg, ibi_cg_c])
+        sig = (sig - np.mean(sig, axis=1, keepdims=True)) / np.std(sig, axis=1, keepdims=True)
+        print(" [OK] Pre-processing complete (Alpha -> FAA -> Downsample -> Crop -> Z-Score)")
+        return {"dyad": dyad, "film": film, "sig": sig, "fs_eeg": fs_eeg,
+                "windows": self._create_windows(sig, self.n_windows, self.window_size)}
+
+    def _finish_items(self, items):
+        """GPU part and output of a batch of prepared items: the windows and the global blocks of ALL of them as one batch
+        per block shape and order (ref :726-772 once per item), then figures and one .npz per item (ref :774-800)."""
+        names4 = ["faa_ch", "ibi_ch", "faa_cg", "ibi_cg"]
+        if not items:
+            return
+        globals_ = [it["sig"] for it in items]
+        if self.ar_p is not None:                       # informational, as in the reference (:726-728)
+            _, _, suggested = self._criterion_for_blocks(globals_, 20, "AIC")
+        blocks, owner = [], []
+        for k, it in enumerate(items):
+            for w in it["windows"]:
+                blocks.append(w); owner.append((k, "w"))
+            blocks.append(it["sig"]); owner.append((k, "g"))
+        orders = self._orders_for_blocks(blocks)
+        ff, sp = self._compute_blocks(blocks, orders, self.fs_ds)
+        for k, it in enumerate(items):
+            dyad, film = it["dyad"], it["film"]
+            mine = [j for j, (kk, _) in enumerate(owner) if kk == k]
+            jw, jg = [j for j in mine if owner[j][1] == "w"], [j for j in mine if owner[j][1] == "g"][0]
+            if self.ar_p is not None:
+                print(f" [INFO] AIC suggested p={suggested[k]} for global signal. Forcing fixed p={self.ar_p}.")
+            out_dir = self.output_ffDTF_folder / dyad
+            print(f" [INFO] Computing windowed ffDTF ({len(jw)} windows)...")
+            ff_w, sp_w, p_w = [ff[j] for j in jw], [sp[j] for j in jw], [orders[j] for j in jw]
+            if self.plot_windowed_enabled or self.save_windowed_enabled:
+                for i in range(len(jw)):
+                    self._figure(dyad, sp_w[i], ff_w[i], self._freqs(), names4, self.plot_windowed_enabled,
+                                 self.save_windowed_enabled, out_dir, f"{dyad}_{film}_win{i}_ffDTF.png")
+            print(" [INFO] Computing global ffDTF...")
+            ff_g, sp_g, p_g = ff[jg], sp[jg], orders[jg]
+            if self.plot_global_enabled or self.save_global_enabled:
+                self._figure(dyad, sp_g, ff_g, self._freqs(), names4, self.plot_global_enabled, self.save_global_enabled,
+                             out_dir, f"{dyad}_{film}_ffDTF_global.png")
+            result = {
+                "mvar": {"ff_dtf_global": ff_g, "spectra_global": sp_g, "ff_dtf_windowed": ff_w,
+                         "spectra_windowed": sp_w, "p_opt_g": p_g, "p_opt_w": p_w},
+                "meta": {"dyad": dyad, "film": film, "fs": self.fs_ds, "fs_original": it["fs_eeg"],
+                         "chan_names": names4, "faa_chan_names": (self.left_chan, self.right_chan),
+                         "windowing": {"n_windows": self.n_windows, "window_size": self.window_size},
+                         "computed_at": datetime.now().isoformat()},
+            }
+            self._save_single_result(dyad, film, result)
+
     def run_pipeline(self):
-        """Per dyad x film: load 4 files, FAA + IBI -> 4 x 480 z-scored block, windowed + global ffDTF /
-        spectra on the GPU, save (ref :661-806).  Missing files are skipped with a [SKIP] line."""
+        """Per dyad x film: load 4 files, FAA + IBI -> 4 x 480 z-scored block, windowed + global ffDTF / spectra, save
+        (ref :661-806).  Missing files are skipped with a [SKIP] line.  The host part runs item by item; the MVAR work of
+        up to `batch_items` items goes to the GPU together (a 4-channel, 160-sample window is ~1 us of arithmetic: one item
+        at a time is pure launch latency); with batch_items = 1 the order of the printed lines is the reference's."""
         if not self.dyads_to_process:
             raise RuntimeError("No loaded dyads. Check the files.")
-        names4 = ["faa_ch", "ibi_ch", "faa_cg", "ibi_cg"]
+        items = []
         for dyad in self.dyads_to_process:
             for film in self.target_events:
-                print(f"--- Processing dyad: {dyad} | Film: {film} ---")
-                paths, missing = {}, []
-                for kind, files in (("EEG", self.eeg_files), ("IBI", self.ibi_files)):
-                    for role in ("ch", "cg"):
-                        path, ok = self._find_file(files, dyad, film, role)
-                        paths[(kind, role)] = path
-                        if not ok:
-                            missing.append(f"{kind} ({role})")
-                if missing:
-                    order = ["EEG (ch)", "IBI (ch)", "EEG (cg)", "IBI (cg)"]
-                    missing.sort(key=order.index)
-                    print(f" [SKIP] Missing files: {', '.join(missing)} -> Skipping {film}")
+                it = self._prepare_item(dyad, film)
+                if it is None:
                     continue
-                for kind, role in (("EEG", "ch"), ("IBI", "ch"), ("EEG", "cg"), ("IBI", "cg")):
-                    print(f" [OK] Loaded {kind} ({role}) : {paths[(kind, role)].name}")
-                _, eeg_ch, fs_eeg, names, ibi_ch, fs_ibi, _ = self._load_eeg_and_ibi(paths[("EEG", "ch")], paths[("IBI", "ch")], role="Child")
-                _, eeg_cg, fs_eeg, names, ibi_cg, fs_ibi, _ = self._load_eeg_and_ibi(paths[("EEG", "cg")], paths[("IBI", "cg")], role="Care Giver")
-                faa_ch, ibi_ch_c = self._preprocess(eeg_ch, fs_eeg, names, ibi_ch, fs_ibi)
-                faa_cg, ibi_cg_c = self._preprocess(eeg_cg, fs_eeg, names, ibi_cg, fs_ibi)
-                sig = np.vstack([faa_ch, ibi_ch_c, faa_cg, ibi_cg_c])
-                sig = (sig - np.mean(sig, axis=1, keepdims=True)) / np.std(sig, axis=1, keepdims=True)
-                print(" [OK] Pre-processing complete (Alpha -> FAA -> Downsample -> Crop -> Z-Score)")
-                if self.ar_p is not None:
-                    _, _, suggested_p = mtmvar.mvar_criterion(sig, 20, "AIC", plot=False, engine=self._engine)
-                    print(f" [INFO] AIC suggested p={suggested_p} for global signal. Forcing fixed p={self.ar_p}.")
-                windows = self._create_windows(sig, self.n_windows, self.window_size)
-                out_dir = self.output_ffDTF_folder / dyad
-                print(f" [INFO] Computing windowed ffDTF ({len(windows)} windows)...")
-                ff_w, sp_w, p_w = self._compute_ffDTF_batch(windows, self.fs_ds)
-                if self.plot_windowed_enabled or self.save_windowed_enabled:
-                    for k in range(len(windows)):
-                        self._figure(dyad, sp_w[k], ff_w[k], self._freqs(), names4, self.plot_windowed_enabled,
-                                     self.save_windowed_enabled, out_dir, f"{dyad}_{film}_win{k}_ffDTF.png")
-                print(" [INFO] Computing global ffDTF...")
-                ff_g, sp_g, p_g = self._compute_ffDTF(dyad, sig, names4, self.fs_ds, plot=self.plot_global_enabled,
-                                                      save_plot=self.save_global_enabled, save_path=out_dir,
-                                                      fig_name=f"{dyad}_{film}_ffDTF_global.png")
-                result = {
-                    "mvar": {"ff_dtf_global": ff_g, "spectra_global": sp_g, "ff_dtf_windowed": ff_w,
-                             "spectra_windowed": sp_w, "p_opt_g": p_g, "p_opt_w": p_w},
-                    "meta": {"dyad": dyad, "film": film, "fs": self.fs_ds, "fs_original": fs_eeg,
-                             "chan_names": names4, "faa_chan_names": (self.left_chan, self.right_chan),
-                             "windowing": {"n_windows": self.n_windows, "window_size": self.window_size},
-                             "computed_at": datetime.now().isoformat()},
-                }
-                self._save_single_result(dyad, film, result)
+                items.append(it)
+                if len(items) >= self.batch_items:
+                    self._finish_items(items)
+                    items = []
+        self._finish_items(items)

@@ -405,7 +405,7 @@ class Engine:
 
     # ------------------------------------------------------------------ recordings streamed from the host
     def stream_dyads(self, dyads, n: int, positions, p: int, freqs, fs: float, bands=None, reduce=None, depth: int = 2,
-                     check="nan", keep_full=None, timeline=None):
+                     check="nan", keep_full=None, timeline=None, out=None):
         """The reference's outer loop -- load a recording, compute, save, next (eeg_alpha_ibi_ffdtf.py:661-806) -- as a
         pipeline: while recording d computes, recording d + 1 crosses PCIe on a copy stream and the reduced result of
         recording d - 1 goes back on another one.  `dyads`: an iterable of host arrays (m, T) float64 -- NumPy arrays
@@ -414,8 +414,10 @@ class Engine:
         ffDTF (windows, m, m, n_bands) of `bands` (`distributed.DEFAULT_BANDS`): full-resolution ffDTF is 5 GB per
         10-minute dyad, i.e. >= 80 ms of PCIe against ~10 ms of compute.  `keep_full(d, ffdtf_device)` is called (on the
         compute stream's timeline) for callers that want to consume the full array on the device.
-        Returns the list of reduced results as NumPy arrays, in order.  Same bits as the resident path: the arithmetic
-        does not know where its input came from (tests/test_gpu_pipeline.py)."""
+        Returns the list of reduced results as NumPy arrays, in order.  `out`: optional pinned host tensor
+        (n_recordings, *reduced shape) that receives the results directly (no host-side copy: at 98 MB per 10-minute
+        dyad that copy alone takes longer than the dyad's compute); the returned arrays are then views of it.  Same
+        bits as the resident path: the arithmetic does not know where its input came from (tests/test_gpu_pipeline.py)."""
         from . import distributed as hdist
         from .sliding import regular_grid, window_items
         dev = self.device
@@ -437,7 +439,7 @@ class Engine:
         def collect_one():
             d, k = pending.popleft()
             slots[k]["d2h"].synchronize()
-            results.append(slots[k]["out_pin"].numpy().copy())
+            results.append(out[d].numpy() if out is not None else slots[k]["out_pin"].numpy().copy())
             if timeline is not None:
                 timeline.append(("collected", d, time.perf_counter()))
 
@@ -477,14 +479,17 @@ class Engine:
             red = reduce(ff)
             if sl["red"] is None or sl["red"].shape != red.shape:
                 sl["red"] = torch.empty_like(red)
-                sl["out_pin"] = torch.empty(red.shape, dtype=red.dtype).pin_memory()
+                if out is None:
+                    sl["out_pin"] = torch.empty(red.shape, dtype=red.dtype).pin_memory()
+                elif not (out.is_pinned() and tuple(out.shape[1:]) == tuple(red.shape) and out.dtype == red.dtype):
+                    raise ValueError("stream_dyads: `out` must be a pinned host tensor (recordings, *%s)" % (tuple(red.shape),))
             elif d >= depth:
                 comp.wait_event(sl["d2h"])                     # (already collected on the host: a formality)
             sl["red"].copy_(red)
             sl["done"].record(comp)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(sl["done"])
-                sl["out_pin"].copy_(sl["red"], non_blocking=True)
+                (out[d] if out is not None else sl["out_pin"]).copy_(sl["red"], non_blocking=True)
                 sl["d2h"].record(s_out)
             pending.append((d, k))
             if timeline is not None:
@@ -529,9 +534,9 @@ class Engine:
                 _lib.check(self.lib.hmv_tf_ffdtf_f64(ar.data_ptr(), c, m, p, tw.data_ptr(), F, ff[sl].data_ptr(),
                                                      den.data_ptr(), H.data_ptr(), info_tf.data_ptr(), self.pivot_tau,
                                                      ws.data_ptr(), nws, 0, 0, 0, self.stream()), "hmv_tf_ffdtf_f64")
-                Sk = self.spectra(H, V, m)
-                _lib.check(self.lib.hmv_transpose_c128(Sk.data_ptr(), S[sl].data_ptr(), c, F, m, self.stream()),
-                           "hmv_transpose_c128")
+                # K5 writes S in the reference's (m, m, F) layout itself (no transposition pass over 16.8 MB per window)
+                _lib.check(self.lib.hmv_spectra_mmf_f64(H.data_ptr(), V.data_ptr(), S[sl].data_ptr(), c, m, F, self.stream()),
+                           "hmv_spectra_mmf_f64")
             t = {"info": info_tf}
             infos.append((info_yw, t["info"]))
         if check:

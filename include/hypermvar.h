@@ -114,6 +114,9 @@ int hmv_transpose_c128(const double* in, double* out, int64_t n_items, int F, in
 
 /* K5.  S[item][f] = H V H^T, plain transpose (src/mtmvar.py:199).  H, S complex128 [item][f][MP][MP]. */
 int hmv_spectra_f64(const double* H, const double* V, double* S, int64_t n_items, int m, int F, void* stream);
+/* The same product written by the kernel itself in the reference's array layout, complex128 [item][m][m][F] (what
+ * multivariate_spectra returns, src/mtmvar.py:165-201) -- no separate hmv_transpose_c128 pass over S. */
+int hmv_spectra_mmf_f64(const double* H, const double* V, double* S, int64_t n_items, int m, int F, void* stream);
 
 /* ---- measures on top of the per-frequency matrices ----------------------------
  * hmv_pack_c128: complex (items, m, m, F) -- the reference's array layout -- to the kernel layout

@@ -46,6 +46,8 @@ bad = [
     lib.hmv_ffdtf_norm_f64(0, D, D, D, 1, 4, 4, 1, 0),
     lib.hmv_transpose_c128(0, D, 1, 4, 4, 0),
     lib.hmv_spectra_f64(0, D, D, 1, 4, 4, 0),
+    lib.hmv_spectra_mmf_f64(D, 0, D, 1, 4, 4, 0),
+    lib.hmv_spectra_mmf_f64(D, D, D, 1, 99, 4, 0),
     lib.hmv_pack_c128(D, 0, 1, 4, 4, 0),
     lib.hmv_cinv_c128(D, 1, 4, 4, D, 0, D, 1.5, 0),
     lib.hmv_partial_coherence_c128(D, 0, D, 1, 4, 4, 0),

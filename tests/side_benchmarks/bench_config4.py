@@ -41,3 +41,30 @@ t0 = time.perf_counter()
 for k in range(200):
     O.full_freq_dtf(x[k], freqs, 8.0, 5); O.multivariate_spectra(x[k], freqs, 8.0, 5)
 print(f"CPU oracle (vectorised NumPy, ffDTF + spectra): {200/(time.perf_counter()-t0):,.0f} windows/s")
+
+# ---- the pipeline mirror itself: dyad x film items per second, batched over items against one item at a time
+import tempfile
+from pathlib import Path
+from hyperscanning_signal_analysis_amd.eeg_alpha_ibi_ffdtf import EEG_IBI_FFDTF_Pipeline
+from tests.test_pipeline_cpu import make_tree
+from tests.test_gpu_pipeline import synthetic_loader
+with tempfile.TemporaryDirectory() as td:
+    td = Path(td)
+    dy = tuple(f"W_{k:03d}" for k in range(1, 101))
+    root = make_tree(td / "data", dyads=dy, films=("Peppa", "Brave"))
+    kw = dict(n_windows=3, ar_p=5, plot_global_enabled=False, save_global_enabled=False, plot_windowed_enabled=False,
+              save_windowed_enabled=False, loader=synthetic_loader)
+    import contextlib, io
+    for bi in (1, 256):
+        pipe = EEG_IBI_FFDTF_Pipeline(root, td / f"o{bi}", ["Peppa", "Brave"], batch_items=bi, **kw)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            items = [pipe._prepare_item(d, f) for d in pipe.dyads_to_process for f in pipe.target_events]
+        t1 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            for k in range(0, len(items), bi):
+                pipe._finish_items(items[k:k + bi])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"run_pipeline, batch_items={bi}: {len(items)} dyad x film items: host DSP {t1 - t0:.2f} s, GPU MVAR + .npz "
+              f"{t2 - t1:.2f} s -> {len(items) / (t2 - t1):,.0f} items/s in the MVAR + output phase")
