@@ -330,12 +330,15 @@ class Engine:
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
                       check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True,
-                      flags: int = 0, grid=None):
+                      flags: int = 0, grid=None, validate: bool = True):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
         check: True raises numpy.linalg.LinAlgError("Singular matrix") if ANY window failed, like the reference's
         np.linalg.solve / inv (the exception names the windows); "nan" returns every window and NaN-fills the
-        failed ones; False skips the check (and its synchronisation).
+        failed ones; False skips the check (and its synchronisation); "mask" returns (out, bad) with `bad` the boolean
+        device mask of the failed windows and no synchronisation (the caller NaN-fills what it keeps).
+        validate=False skips the bounds check of the window descriptors and of a declared grid (two host
+        synchronisations): for callers that validated the same descriptors before (`stream_dyads`).
         overlap: give the library a second stream: the Yule-Walker stage (K2), whose launches cannot fill the
         chip, then runs as two half-batches that interleave on the device (see include/hypermvar.h).
         flags: option bits of include/hypermvar.h (`_lib.FLAG_*`); 0 = the fast defaults.
@@ -350,7 +353,8 @@ class Engine:
         x = x if x.stride(2) == 1 else x.contiguous()
         n_rec, m, T = x.shape
         mp = self.pad(m)
-        self.check_items(x, item_rec, item_start, n, p)
+        if validate:
+            self.check_items(x, item_rec, item_start, n, p)
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
@@ -377,7 +381,8 @@ class Engine:
             if g_nwin < 1 or n_items % g_nwin or g_hop < 1 or n_items // g_nwin > n_rec:
                 raise ValueError("grid = (hop, first, n_win) does not match the number of items / recordings")
             k = torch.arange(n_items, dtype=torch.int64, device=self.device)
-            same = torch.equal(item_rec, k // g_nwin) and torch.equal(item_start, g_first + (k % g_nwin) * g_hop)
+            same = (not validate) or (torch.equal(item_rec, k // g_nwin) and
+                                      torch.equal(item_start, g_first + (k % g_nwin) * g_hop))
             if not same:
                 raise ValueError("grid = (hop, first, n_win) contradicts item_rec / item_start "
                                  "(items must be recording-major, window-minor on the declared grid)")
@@ -392,9 +397,8 @@ class Engine:
             badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
             if bool(badw.any()):
                 out[badw] = float("nan")
-        elif check == "nan-async":  # the same without a host synchronisation (streamed recordings)
-            badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
-            out.masked_fill_(badw.view(-1, 1, 1, 1), float("nan"))
+        elif check == "mask":       # no host synchronisation: the caller decides what to NaN-fill (streamed recordings)
+            return out, (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
         elif check:
             self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
             self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
@@ -430,6 +434,7 @@ class Engine:
         pos = np.asarray(positions, dtype=np.int64)
         item_rec, item_start = window_items(1, pos, dev)
         grid = regular_grid(pos, n, p)
+        validated = False                    # the descriptors are the same for every recording: checked once
         import collections
         import time
         comp = torch.cuda.current_stream(dev)
@@ -472,11 +477,16 @@ class Engine:
                 sl["x"][0].copy_(src, non_blocking=True)
                 sl["h2d"].record(s_in)
             comp.wait_event(sl["h2d"])
-            ff = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["ff"],
-                                    check="nan-async" if check == "nan" else False, grid=grid)
+            ff, bad = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["ff"], check="mask", grid=grid,
+                                         validate=not validated)
+            validated = True
             if keep_full is not None:
+                if check == "nan":
+                    ff.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
                 keep_full(d, ff)
             red = reduce(ff)
+            if check == "nan" and red.shape[0] == bad.shape[0]:     # NaN-fill what leaves the device (98 MB, not 5 GB)
+                red.masked_fill_(bad.view(-1, *([1] * (red.dim() - 1))), float("nan"))
             if sl["red"] is None or sl["red"].shape != red.shape:
                 sl["red"] = torch.empty_like(red)
                 if out is None:

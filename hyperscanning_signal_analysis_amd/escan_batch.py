@@ -37,7 +37,7 @@ from .eeg_io import filter_eeg
 from .engine import default_engine
 from .sliding import hop_positions, regular_grid, window_items
 
-__all__ = ["discover_dyads", "decode_events", "segment_block", "run", "xarray_reader"]
+__all__ = ["discover_dyads", "decode_events", "segment_block", "prepare_dyad", "run", "xarray_reader"]
 
 ROLES = (("ch", "child"), ("cg", "caregiver"))
 _FILE_RE = re.compile(r"^(?P<dyad>.+)_EEG_(?P<role>ch|cg)_(?P<task>.+)$")
@@ -118,17 +118,64 @@ def segment_block(child, caregiver, start_s, duration_s, low_cutoff_hz=None, hig
     return np.vstack([p[:, :T] for p in parts]), names, fss[0]
 
 
+def prepare_dyad(dyad, files_by_task, reader, low_cutoff_hz=None, high_cutoff_hz=None, channel_subset=None, say=None):
+    """Host part of one dyad: every task file is read and filtered ONCE (both members), then cut into its events, z-scored
+    per segment and stacked child on caregiver.  Returns {"segments": [{task, event, start_s, duration_s, block, names, fs}],
+    "notes": [printed lines], "host_s": seconds}.  Pure NumPy / SciPy: runs in a worker thread beside the GPU work of the
+    previous dyad (filtfilt releases the GIL)."""
+    t0 = time.perf_counter()
+    segs, notes = [], []
+    for task, files in sorted(files_by_task.items()):
+        if "ch" not in files or "cg" not in files:
+            notes.append(f"[SKIP] {dyad} {task}: missing {'child' if 'ch' not in files else 'caregiver'} file")
+            continue
+        recs = {r: reader(files[r]) for r in ("ch", "cg")}
+        filt = {}
+        for r in ("ch", "cg"):
+            x, ch, t, fs = _filtered(recs[r], low_cutoff_hz, high_cutoff_hz)         # whole file, once
+            if channel_subset is not None:
+                idx = [ch.index(c) for c in channel_subset if c in ch]
+                if not idx:
+                    raise ValueError(f"None of the requested channels {channel_subset} found. Available: {ch}")
+                x, ch = x[:, idx], [ch[k] for k in idx]
+            filt[r] = (x, ch, t, fs)
+        if filt["ch"][3] != filt["cg"][3]:
+            raise ValueError(f"sampling rates differ: {filt['ch'][3]} vs {filt['cg'][3]}")
+        for name, start, dur in decode_events(recs["ch"]["attrs"]):
+            parts, names = [], []
+            for r in ("ch", "cg"):
+                x, ch, t, fs = filt[r]
+                mask = (t >= start) & (t <= start + dur)
+                seg = np.ascontiguousarray(x[mask].T)
+                sd = np.std(seg, axis=1, keepdims=True)
+                sd[sd == 0] = 1.0
+                parts.append((seg - np.mean(seg, axis=1, keepdims=True)) / sd)
+                names += [f"{c}_{r}" for c in ch]
+            T = min(q.shape[1] for q in parts)
+            segs.append({"task": task, "event": name, "start_s": start, "duration_s": dur, "fs": filt["ch"][3],
+                         "block": np.vstack([q[:, :T] for q in parts]), "names": names})
+    return {"segments": segs, "notes": notes, "host_s": time.perf_counter() - t0}
+
+
 def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, freqs=None, bands=hdist.DEFAULT_BANDS,
         low_cutoff_hz=None, high_cutoff_hz=None, channel_subset=None, with_psd=False, psd_fmin=1.0, psd_fmax=30.0,
         psd_bandwidth=2.0, save_full=False, skip_existing=True, reader=None, engine=None, world=1, rank=0,
-        verbose=True):
+        verbose=True, prefetch=2, timing=None):
     """Process every dyad under <root>/EEG.  Per dyad one `<out_dir>/<dyad>_ffdtf.npz` with, per segment `<task>/<event>`:
         <seg>/ffdtf_bands   (windows, n, n, n_bands)   band-integrated ffDTF of every window
         <seg>/ffdtf         (windows, n, n, F)         only with save_full=True (8.4 MB per window at 64 channels)
         <seg>/starts        (windows,)                 first sample of every window inside the segment
         <seg>/psd, <seg>/psd_freqs                     multitaper PSD of the segment block (with_psd=True)
-      plus `channels`, `freqs`, `meta` (JSON).  Returns {"done": [...], "skipped": [...], "failed": [(dyad, error)]}.
-    A window whose fit is singular is NaN-filled, not fatal (the reference would raise and lose the dyad)."""
+      plus `channels`, `freqs`, `meta` (JSON).  Returns {"done": [...], "skipped": [...], "failed": [(dyad, error)],
+      "timing": {...}}.
+    A window whose fit is singular is NaN-filled, not fatal (the reference would raise and lose the dyad); a segment that
+    cannot be processed is logged in the dyad's meta and does not discard the dyad's other segments.
+    Pipeline: reading + filtering + cutting of the next `prefetch` dyads runs in worker threads while the GPU works on the
+    current one (every task file is filtered once, not once per event); per segment the block crosses PCIe once and the
+    PSD runs on a second HIP stream beside the MVAR kernels.  `timing` (optional dict) receives the host / GPU split."""
+    import concurrent.futures as cf
+
+    import torch
     eng = engine or default_engine()
     reader = reader or xarray_reader
     out_dir = Path(out_dir)
@@ -139,65 +186,115 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
     mine = [dyads[k] for k in hdist.shard_dyads(len(dyads), world, rank)]
     say(f"[INFO] {len(dyads)} dyads under {root}; rank {rank}/{world} takes {len(mine)}")
     done, skipped, failed = [], [], []
+    todo = []
     for dyad in mine:
-        target = out_dir / f"{dyad}_ffdtf.npz"
-        if skip_existing and target.exists():
-            say(f"[SKIP] {dyad}: {target.name} exists")
+        if skip_existing and (out_dir / f"{dyad}_ffdtf.npz").exists():
+            say(f"[SKIP] {dyad}: {dyad}_ffdtf.npz exists")
             skipped.append(dyad)
-            continue
-        try:
-            result, meta = {}, {"dyad": dyad, "segments": [], "model_order": int(model_order), "window_s": window_s,
-                                "overlap": overlap, "created": time.strftime("%Y-%m-%dT%H:%M:%S")}
-            names_out, freqs_out = None, None
-            for task, files in sorted(tree[dyad].items()):
-                if "ch" not in files or "cg" not in files:
-                    say(f"[SKIP] {dyad} {task}: missing {'child' if 'ch' not in files else 'caregiver'} file")
-                    continue
-                recs = {r: reader(files[r]) for r in ("ch", "cg")}
-                for name, start, dur in decode_events(recs["ch"]["attrs"]):
-                    block, names, fs = segment_block(recs["ch"], recs["cg"], start, dur, low_cutoff_hz, high_cutoff_hz,
-                                                     channel_subset)
-                    W = int(round(window_s * fs))
-                    hop = max(1, int(round(W * (1.0 - overlap))))
-                    T = block.shape[1]
-                    if T < W:
-                        say(f"[SKIP] {dyad} {task}/{name}: {T} samples < one window ({W})")
-                        continue
-                    pos = hop_positions(T, W, hop)       # fixed hop; the tail shorter than one hop is dropped
-                    n_win = len(pos)
-                    f = np.asarray(freqs if freqs is not None else np.arange(0.5, min(fs / 2.0, 128.0) + 1e-9, 0.5))
-                    xd = eng.to_device(block[None])
-                    rec_i, st_i = window_items(1, pos, eng.device)
-                    ff = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="nan",
-                                           grid=regular_grid(pos, W, int(model_order)))
-                    lo, hi = hdist.band_bins(f, bands)
-                    key = f"{task}/{name}"
-                    result[f"{key}/ffdtf_bands"] = eng.band_sums(ff, lo, hi).cpu().numpy()
-                    if save_full:
+        else:
+            todo.append(dyad)
+    tm = {"wall_s": 0.0, "host_prepare_s": 0.0, "wait_for_host_s": 0.0, "gpu_s": 0.0, "save_s": 0.0, "dyads": []}
+    t_all = time.perf_counter()
+    psd_stream = torch.cuda.Stream(eng.device) if with_psd else None
+    pool = cf.ThreadPoolExecutor(max_workers=max(1, int(prefetch)))
+    futures = {}
+
+    def submit(k):
+        if k < len(todo) and k not in futures:
+            futures[k] = pool.submit(prepare_dyad, todo[k], tree[todo[k]], reader, low_cutoff_hz, high_cutoff_hz, channel_subset)
+
+    for k in range(min(len(todo), max(1, int(prefetch)))):
+        submit(k)
+    try:
+        for k, dyad in enumerate(todo):
+            target = out_dir / f"{dyad}_ffdtf.npz"
+            try:
+                tw = time.perf_counter()
+                prep = futures.pop(k).result()
+                wait_s = time.perf_counter() - tw
+                submit(k + max(1, int(prefetch)))
+                for line in prep["notes"]:
+                    say(line)
+                result, meta = {}, {"dyad": dyad, "segments": [], "failed_segments": [], "model_order": int(model_order),
+                                    "window_s": window_s, "overlap": overlap, "created": time.strftime("%Y-%m-%dT%H:%M:%S")}
+                names_out, freqs_out = None, None
+                tg = time.perf_counter()
+                pending = []                                       # device results of this dyad, fetched after the last launch
+                for seg in prep["segments"]:
+                    key = f"{seg['task']}/{seg['event']}"
+                    try:
+                        block, fs = seg["block"], seg["fs"]
+                        W = int(round(window_s * fs))
+                        hop = max(1, int(round(W * (1.0 - overlap))))
+                        T = block.shape[1]
+                        if T < W:
+                            say(f"[SKIP] {dyad} {key}: {T} samples < one window ({W})")
+                            continue
+                        pos = hop_positions(T, W, hop)            # fixed hop; the tail shorter than one hop is dropped
+                        f = np.asarray(freqs if freqs is not None else np.arange(0.5, min(fs / 2.0, 128.0) + 1e-9, 0.5))
+                        xd = eng.to_device(block[None])
+                        rec_i, st_i = window_items(1, pos, eng.device)
+                        psd_dev = None
+                        if with_psd:                               # second stream, same resident block
+                            from .psd import compute_psd_multitaper_device
+                            psd_stream.wait_stream(torch.cuda.current_stream(eng.device))
+                            with torch.cuda.stream(psd_stream):
+                                pf, psd_dev = compute_psd_multitaper_device(xd[0], fs, psd_fmin, psd_fmax, psd_bandwidth, engine=eng)
+                            xd.record_stream(psd_stream)
+                        ff, bad = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="mask",
+                                                    grid=regular_grid(pos, W, int(model_order)))
+                        lo, hi = hdist.band_bins(f, bands)
+                        bsum = eng.band_sums(ff, lo, hi)
+                        bsum.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
+                        if save_full:
+                            ff.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
+                        pending.append((seg, key, pos, W, f, bsum, ff if save_full else None, bad, psd_dev, pf if with_psd else None))
+                    except Exception as e:                         # one bad segment does not discard the dyad
+                        meta["failed_segments"].append({"segment": key, "error": f"{type(e).__name__}: {e}"})
+                        say(f"Failed segment: {dyad} {key} -> {e}")
+                if psd_stream is not None:
+                    torch.cuda.current_stream(eng.device).wait_stream(psd_stream)
+                for seg, key, pos, W, f, bsum, ff, bad, psd_dev, pf in pending:
+                    result[f"{key}/ffdtf_bands"] = bsum.cpu().numpy()
+                    if ff is not None:
                         result[f"{key}/ffdtf"] = ff.cpu().numpy()
                     result[f"{key}/starts"] = np.asarray(pos)
-                    if with_psd:
-                        from .psd import compute_psd_multitaper
-                        pf, psd = compute_psd_multitaper(block, fs, psd_fmin, psd_fmax, psd_bandwidth, engine=eng)
-                        result[f"{key}/psd"], result[f"{key}/psd_freqs"] = psd, pf
-                    n_bad = int(np.isnan(result[f"{key}/ffdtf_bands"]).any(axis=(1, 2, 3)).sum())
-                    meta["segments"].append({"task": task, "event": name, "start_s": start, "duration_s": dur, "fs": fs,
-                                             "samples": int(T), "windows": int(n_win), "window": int(W),
-                                             "singular_windows": n_bad})
-                    names_out, freqs_out = names, f
-                    say(f"[OK] {dyad} {key}: {block.shape[0]} ch x {T} samples, {n_win} windows"
+                    if psd_dev is not None:
+                        result[f"{key}/psd"], result[f"{key}/psd_freqs"] = psd_dev.cpu().numpy(), pf
+                    n_bad = int(bad.sum().item())
+                    T = seg["block"].shape[1]
+                    meta["segments"].append({"task": seg["task"], "event": seg["event"], "start_s": seg["start_s"],
+                                             "duration_s": seg["duration_s"], "fs": seg["fs"], "samples": int(T),
+                                             "windows": int(len(pos)), "window": int(W), "singular_windows": n_bad})
+                    names_out, freqs_out = seg["names"], f
+                    say(f"[OK] {dyad} {key}: {seg['block'].shape[0]} ch x {T} samples, {len(pos)} windows"
                         + (f", {n_bad} singular" if n_bad else ""))
-            if not meta["segments"]:
-                say(f"[SKIP] {dyad}: no complete child + caregiver segment")
-                skipped.append(dyad)
-                continue
-            np.savez_compressed(target, channels=np.asarray(names_out), freqs=freqs_out,
-                                bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
-            say(f"[SAVED] {target}")
-            done.append(dyad)
-        except Exception as e:                      # one bad dyad does not stop the batch (export_..._batch.py:93-99)
-            failed.append((dyad, f"{type(e).__name__}: {e}"))
-            say(f"Failed: {dyad} -> {e}")
+                torch.cuda.synchronize(eng.device)
+                gpu_s = time.perf_counter() - tg
+                if not meta["segments"]:
+                    say(f"[SKIP] {dyad}: no complete child + caregiver segment")
+                    skipped.append(dyad)
+                    continue
+                ts = time.perf_counter()
+                np.savez_compressed(target, channels=np.asarray(names_out), freqs=freqs_out,
+                                    bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
+                save_s = time.perf_counter() - ts
+                say(f"[SAVED] {target}")
+                done.append(dyad)
+                tm["host_prepare_s"] += prep["host_s"]; tm["wait_for_host_s"] += wait_s
+                tm["gpu_s"] += gpu_s; tm["save_s"] += save_s
+                tm["dyads"].append({"dyad": dyad, "host_prepare_s": prep["host_s"], "waited_for_host_s": wait_s,
+                                    "gpu_s": gpu_s, "save_s": save_s, "segments": len(meta["segments"])})
+            except Exception as e:                  # one bad dyad does not stop the batch (export_..._batch.py:93-99)
+                failed.append((dyad, f"{type(e).__name__}: {e}"))
+                say(f"Failed: {dyad} -> {e}")
+                submit(k + max(1, int(prefetch)))
+    finally:
+        pool.shutdown(wait=True, cancel_futures=True)
+    tm["wall_s"] = time.perf_counter() - t_all
+    tm["gpu_busy_fraction_of_wall"] = tm["gpu_s"] / tm["wall_s"] if tm["wall_s"] > 0 else 0.0
+    if timing is not None:
+        timing.update(tm)
     say(f"Finished. Success: {len(done)}, Skipped: {len(skipped)}, Failed: {len(failed)}")
     with open(out_dir / ("batch.log" if world == 1 else f"batch_rank{rank}.log"), "a", encoding="utf-8") as log:
         log.write(f"Finished. Success: {len(done)}, Skipped: {len(skipped)}, Failed: {len(failed)}\n")
@@ -205,4 +302,4 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
             log.write("Failed dyads:\n")
             for dyad, err in failed:
                 log.write(f"  - {dyad}: {err}\n")
-    return {"done": done, "skipped": skipped, "failed": failed}
+    return {"done": done, "skipped": skipped, "failed": failed, "timing": tm}

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .engine import default_engine
 
-__all__ = ["compute_psd_multitaper", "average_psd_across_conditions", "dpss_device"]
+__all__ = ["compute_psd_multitaper", "compute_psd_multitaper_device", "average_psd_across_conditions", "dpss_device"]
 
 
 def _taper_cache_dir():
@@ -92,6 +92,34 @@ def _tapers(n_times: int, half_nbw: float, eng):
         except OSError:                # read-only or full disk: the cache is an optimisation only
             pass
     return out
+
+
+def compute_psd_multitaper_device(xd: torch.Tensor, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30,
+                                  engine=None):
+    """(freqs (host), psd (device tensor (n_channels, n_freqs))) of a block that already sits on the device, on the
+    CURRENT stream and without a host copy: what the batch front-end runs beside the MVAR work of the same block."""
+    eng = engine or default_engine()
+    assert xd.dim() == 2 and xd.dtype == torch.float64 and xd.is_cuda and xd.stride(1) == 1
+    n_ch, n_times = xd.shape
+    half_nbw = float(bandwidth) * n_times / (2.0 * float(sfreq))
+    td, wd = _tapers(n_times, half_nbw, eng)
+    K = td.shape[0]
+    freqs = np.fft.rfftfreq(n_times, 1.0 / float(sfreq))
+    sel = np.flatnonzero((freqs >= fmin) & (freqs <= fmax))
+    if sel.size == 0:
+        return freqs[sel], eng.empty(n_ch, 0)
+    lo, hi = int(sel[0]), int(sel[-1])
+    per_ch = int(eng.lib.hmv_psd_workspace_bytes(1, n_times, K))
+    ch_chunk = int(max(1, min(n_ch, max_workspace_bytes // max(per_ch, 1))))
+    nbytes = int(eng.lib.hmv_psd_workspace_bytes(ch_chunk, n_times, K))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)
+    out = eng.empty(n_ch, hi - lo + 1)
+    with torch.cuda.device(eng.device):
+        rc = eng.lib.hmv_psd_multitaper_f64(xd.data_ptr(), n_ch, n_times, xd.stride(0), td.data_ptr(), wd.data_ptr(), K,
+                                            lo, hi, out.data_ptr(), ws.data_ptr(), nbytes, ch_chunk, eng.stream())
+    _lib.check(rc, "hmv_psd_multitaper_f64")
+    ws.record_stream(torch.cuda.current_stream(eng.device))
+    return freqs[lo:hi + 1], out
 
 
 def compute_psd_multitaper(data, sfreq, fmin, fmax, bandwidth, max_workspace_bytes: int = 8 << 30, engine=None):

@@ -104,3 +104,70 @@ def test_batch_matches_oracle_per_window_and_keeps_books(tree, tmp_path, capsys)
     r1 = EB.run(tree, tmp_path / "o2", model_order=3, freqs=freqs, reader=_reader, world=2, rank=1, verbose=False)
     assert r0["done"] == ["W_003", "W_010"] and r1["done"] == [] and [d for d, _ in r1["failed"]] == ["W_030"]
     assert (tmp_path / "o2" / "batch_rank1.log").exists()
+
+
+def _write_full(path, seed, fs, dur_s, events, n_eeg=32):
+    """one exported task file at BASELINE config-5 size: 32 EEG channels + the two mastoids at 500 Hz"""
+    rng = np.random.default_rng(seed)
+    chans = [f"E{k:02d}" for k in range(n_eeg)] + ["M1", "M2"]
+    n = int(dur_s * fs)
+    t = np.arange(n) / fs - 2.0
+    x = rng.standard_normal((n, len(chans)))
+    x[1:] += 0.7 * x[:-1]
+    x[:, 1:n_eeg] += 0.2 * x[:, :n_eeg - 1]
+    ev = [{"name": nm, "start_s": 50.0 + st, "start_rel_s": st, "duration_s": du} for nm, st, du in events]
+    attrs = {"sampling_freq": fs, "task_events_structure": json.dumps(ev)}
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with open(path, "wb") as f:
+        np.savez(f, data=x, time=t, channels=np.asarray(chans), attrs=json.dumps(attrs), events=json.dumps(ev))
+
+
+def make_config5_tree(root, dyads, fs=500.0):
+    """SECORE (one 220 s event, /root/reference/src/secore_loader.py:117), passive movies (three films) and a free talk"""
+    tasks = {"secore": (230.0, [("secore", 1.0, 220.0)]),
+             "passive_movies": (215.0, [("Peppa", 1.0, 60.0), ("Incredibles", 70.0, 60.0), ("Brave", 140.0, 60.0)]),
+             "talk": (190.0, [("talk_1", 1.0, 180.0)])}
+    for d, dy in enumerate(dyads):
+        for r, (code, role) in enumerate((("ch", "child"), ("cg", "caregiver"))):
+            for k, (task, (dur, ev)) in enumerate(tasks.items()):
+                _write_full(Path(root) / "EEG" / dy / role / f"{dy}_EEG_{code}_{task}.nc", 1000 * d + 10 * k + r, fs, dur, ev)
+    return Path(root)
+
+
+from pathlib import Path  # noqa: E402
+
+
+def test_config5_full_size_dyad(tmp_path):
+    """ONE dyad at BASELINE config-5 size -- 2 x 32 channels at 500 Hz, SECORE 220 s + three 60 s films + 180 s of talk,
+    2 s windows with 50 % overlap, p = 8, 256 frequencies, multitaper PSD beside it -- through the pipelined front-end:
+    every task file filtered once, 5 segments, 575 windows; spot windows against the oracle on the block the front-end
+    built, every ffDTF row of every window sums to one (band sums add up), the host / GPU time split is reported."""
+    root = make_config5_tree(tmp_path / "tree", ["W_101"])
+    out = tmp_path / "out"
+    timing = {}
+    res = EB.run(root, out, window_s=2.0, overlap=0.5, model_order=8, low_cutoff_hz=1.0, high_cutoff_hz=45.0,
+                 with_psd=True, psd_fmin=1.0, psd_fmax=30.0, psd_bandwidth=2.0, reader=_reader, verbose=False, timing=timing,
+                 bands=((0.5, 4.0), (4.0, 8.0), (8.0, 13.0), (13.0, 30.0), (30.0, 128.5)))
+    assert res["done"] == ["W_101"] and not res["failed"]
+    z = np.load(out / "W_101_ffdtf.npz", allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    assert [s["event"] for s in meta["segments"]] == ["Peppa", "Incredibles", "Brave", "secore", "talk_1"]
+    assert [s["windows"] for s in meta["segments"]] == [59, 59, 59, 219, 179] and not meta["failed_segments"]
+    assert len(z["channels"]) == 64 and len(z["freqs"]) == 256
+    found = EB.discover_dyads(root)
+    for seg in (meta["segments"][0], meta["segments"][3]):
+        key = f"{seg['task']}/{seg['event']}"
+        recs = {r: _reader(found["W_101"][seg["task"]][r]) for r in ("ch", "cg")}
+        block, names, fs = EB.segment_block(recs["ch"], recs["cg"], seg["start_s"], seg["duration_s"], 1.0, 45.0)
+        assert block.shape == (64, seg["samples"]) and fs == 500.0
+        bands, starts = z[f"{key}/ffdtf_bands"], z[f"{key}/starts"]
+        assert bands.shape == (seg["windows"], 64, 64, 5) and np.isfinite(bands).all()
+        # the five bands tile the whole grid: every row of every window sums to one
+        assert np.abs(bands.sum(axis=(2, 3)) - 1.0).max() < 1e-12
+        lo, hi = hd.band_bins(z["freqs"])
+        for k in (0, len(starts) // 2, len(starts) - 1):
+            ref = O.full_freq_dtf(block[:, starts[k]:starts[k] + 1000], z["freqs"], fs, 8)
+            refb = np.stack([ref[..., a:b].sum(-1) for a, b in zip(lo, hi)], axis=-1)
+            assert np.abs(bands[k] - refb).max() / np.abs(refb).max() < 1e-9
+        assert z[f"{key}/psd"].shape[0] == 64 and (z[f"{key}/psd"] > 0).all()
+    assert timing["host_prepare_s"] > 0 and timing["gpu_s"] > 0 and 0 < timing["gpu_busy_fraction_of_wall"] <= 1

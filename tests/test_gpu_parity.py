@@ -391,7 +391,7 @@ def test_two_stream_overlap_is_bit_identical():
     b = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, overlap=True, flags=T)     # 12 + 11 windows
     c = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=5, overlap=False, flags=T)
     d = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=17, overlap=True, flags=T)     # 9 + 8, then 6 unsplit
-    e = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23)                   # default: K2 in one launch
+    e = eng.sliding_ffdtf(xd, rec, st, w, 8, freqs, 500.0, chunk=23, flags=_lib.FLAG_YW_ONE_LAUNCH)   # block LDL^T in one launch
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(a, e)
 
