@@ -290,10 +290,18 @@ class Engine:
         """(..., F) -> (..., n_bands): sums over the bin ranges [bin_lo[b], bin_hi[b])."""
         F = ff.shape[-1]
         ff = ff.contiguous()
-        lo = torch.as_tensor(np.asarray(bin_lo, dtype=np.int32)).to(self.device)
-        hi = torch.as_tensor(np.asarray(bin_hi, dtype=np.int32)).to(self.device)
-        if bool((lo < 0).any()) or bool((hi > F).any()) or bool((hi < lo).any()):
+        lo_h, hi_h = np.asarray(bin_lo, dtype=np.int32), np.asarray(bin_hi, dtype=np.int32)
+        if (lo_h < 0).any() or (hi_h > F).any() or (hi_h < lo_h).any() or lo_h.shape != hi_h.shape:
             raise ValueError("band bin ranges must satisfy 0 <= lo <= hi <= F")
+        # the bin tables live on the device per distinct band set: a fresh pageable-memory copy per call is a synchronous
+        # copy on the compute stream, i.e. a host wait for everything queued before it (the streamed path's stall)
+        key = (lo_h.tobytes(), hi_h.tobytes())
+        cache = self.__dict__.setdefault("_band_tables", {})
+        if key not in cache:
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            cache[key] = (torch.as_tensor(lo_h).to(self.device), torch.as_tensor(hi_h).to(self.device))
+        lo, hi = cache[key]
         nb = int(lo.numel())
         rows = ff.numel() // F if F else 0
         out = self.empty(*ff.shape[:-1], nb)

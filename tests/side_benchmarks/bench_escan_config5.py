@@ -21,7 +21,7 @@ with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, f"out_{pf}_{int(psd)}")
         if pf == 1:                                   # the first pass also pays the DPSS tapers (cached afterwards)
             EB.run(root, os.path.join(td, "warm"), tasks=("talk",), with_psd=True, reader=_reader, verbose=False, prefetch=1)
-        res = EB.run(root, out, window_s=2.0, overlap=0.5, model_order=8, low_cutoff_hz=1.0, high_cutoff_hz=45.0,
+        res = EB.run(root, out, window_s=2.0, overlap=0.5, model_order=8, low_cutoff_hz=1.0, high_cutoff_hz=120.0,
                      with_psd=psd, psd_fmin=1.0, psd_fmax=30.0, psd_bandwidth=2.0, reader=_reader, verbose=False,
                      timing=timing, prefetch=pf)
         assert len(res["done"]) == n_dyads, res
