@@ -254,7 +254,7 @@ def main():
     e2e_res = None
     side = (world == 1 and not strong and not args.no_side)
     if side:
-        E = args.stream_dyads or max(8, D)
+        E = args.stream_dyads or max(16, D)
         feed_src = [torch.from_numpy(xh).pin_memory() for xh in x_hosts]          # what a loader would hand over
         feed = [feed_src[d % len(feed_src)] for d in range(E)]
         nb = len(hdist.DEFAULT_BANDS)

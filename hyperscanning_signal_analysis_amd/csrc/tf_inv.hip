@@ -51,6 +51,16 @@ namespace hmv {
 #define HMV_K3_WGS 4
 #endif
 
+// Row worker payload loads: 1 = device-scope (sc1) buffer loads -- the pairing the memory model asks for with the
+// write-through (sc1) publish stores -- 0 = non-temporal loads (L2-served, bypassing this CU's L1 like sc1 loads; every
+// line is written write-through before `ready` is raised and read exactly once per launch).  Same-box A/B, three
+// interleaved rounds (profiles/r03_k3_ab_notes.md): sc1 7.78 / 7.72 / 7.71 ms, nt 7.64 / 7.52 / 7.53 ms -- the sc1 form
+// costs 2.3 % of K3, above the 1 % it was allowed, so the nt form stays the default; bench.py re-checks the whole
+// 5 GB output against the separate K4 pass after every run, and `make SC1=1` builds the other form.
+#ifndef HMV_ROW_LOADS_SC1
+#define HMV_ROW_LOADS_SC1 0
+#endif
+
 #define HMV_LDS_FENCE()                                     \
   do {                                                      \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -172,15 +182,34 @@ __device__ __forceinline__ void normalise_row(const TfArgs& a, int item, int i, 
   const int total = (F / FC) * NJC;
   const int fr = l / J2, j2 = l - fr * J2;           // load side: FR frequency rows x J2 column pairs per instruction
   const int f2 = l & 7, jr = l >> 3;                 // store side: 8 frequency pairs x 8 columns per instruction
+#if !HMV_ROW_LOADS_SC1
   const double* Pw = a.P + ((size_t)item * MP + i) * F * MP + (size_t)fr * MP + 2 * j2;     // Pp[item][i][f][j]
+#endif
   double* ow = a.ff + ((size_t)item * m + i) * m * F + (size_t)jr * F + 2 * f2;
+#if HMV_ROW_LOADS_SC1
+  // The slab was written by OTHER workgroups of this launch with write-through (sc1) stores and is read here with
+  // device-scope (sc1) loads -- the pairing the memory model asks for (MI355X_MICROARCH.md, inter-workgroup visibility:
+  // every store and every load of the handed-off bytes sc1, stores drained before the flag) -- as buffer loads, which
+  // hipcc counts in its own s_waitcnt bookkeeping (an asm global_load ... sc1 would not be).  One descriptor per row slab
+  // (128 KB: 32-bit offsets suffice).  Measured against the non-temporal loads of round 2: profiles/r03_k3_ab_notes.md.
+  const double* slab = a.P + ((size_t)item * MP + i) * F * MP;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(slab), 0, F * MP * 8, 0x00020000);
+  const int off0 = (fr * MP + 2 * j2) * 8;
+#endif
   auto issue = [&](f64x2 (&v)[NL], int u) __attribute__((always_inline)) {
     if (u < total) {
       const int jc = u % NJC, f0 = (u / NJC) * FC;
+#if HMV_ROW_LOADS_SC1
+      const int off = off0 + (f0 * MP + jc * JC) * 8;
+#pragma unroll
+      for (int k = 0; k < NL; ++k)
+        v[k] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, off + k * FR * MP * 8, 0, 16 /* sc1 */));
+#else
       const double* src = Pw + (size_t)f0 * MP + jc * JC;
 #pragma unroll
       for (int k = 0; k < NL; ++k)
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src + (size_t)(k * FR) * MP));
+#endif
     }
   };
   auto drain = [&](const f64x2 (&v)[NL], int u) __attribute__((always_inline)) {

@@ -196,8 +196,8 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
     tm = {"wall_s": 0.0, "host_prepare_s": 0.0, "wait_for_host_s": 0.0, "gpu_s": 0.0, "save_s": 0.0, "dyads": []}
     t_all = time.perf_counter()
     psd_stream = torch.cuda.Stream(eng.device) if with_psd else None
-    pool = cf.ThreadPoolExecutor(max_workers=max(1, int(prefetch)))
-    futures = {}
+    pool = cf.ThreadPoolExecutor(max_workers=max(2, int(prefetch) + 1))
+    futures, saves = {}, []
 
     def submit(k):
         if k < len(todo) and k not in futures:
@@ -275,11 +275,17 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                     say(f"[SKIP] {dyad}: no complete child + caregiver segment")
                     skipped.append(dyad)
                     continue
-                ts = time.perf_counter()
-                np.savez_compressed(target, channels=np.asarray(names_out), freqs=freqs_out,
-                                    bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
-                save_s = time.perf_counter() - ts
-                say(f"[SAVED] {target}")
+                # the compressed write (2 - 3 s per full-size dyad, zlib outside the GIL) goes to the worker pool as well:
+                # the GPU and the next dyad's host work do not wait for it
+                def _save(target=target, names_out=names_out, freqs_out=freqs_out, meta=meta, result=result):
+                    t0 = time.perf_counter()
+                    tmp = target.with_suffix(".tmp.npz")
+                    np.savez_compressed(tmp, channels=np.asarray(names_out), freqs=freqs_out,
+                                        bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
+                    tmp.replace(target)                       # a file that exists is complete (skip-if-exists relies on it)
+                    return time.perf_counter() - t0
+                saves.append((dyad, target, pool.submit(_save)))
+                save_s = 0.0
                 done.append(dyad)
                 tm["host_prepare_s"] += prep["host_s"]; tm["wait_for_host_s"] += wait_s
                 tm["gpu_s"] += gpu_s; tm["save_s"] += save_s
@@ -289,6 +295,14 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                 failed.append((dyad, f"{type(e).__name__}: {e}"))
                 say(f"Failed: {dyad} -> {e}")
                 submit(k + max(1, int(prefetch)))
+        for dyad, target, fut in saves:                   # every file on disk before the call returns
+            try:
+                tm["save_s"] += fut.result()
+                say(f"[SAVED] {target}")
+            except Exception as e:
+                done.remove(dyad)
+                failed.append((dyad, f"{type(e).__name__}: {e}"))
+                say(f"Failed: {dyad} -> {e}")
     finally:
         pool.shutdown(wait=True, cancel_futures=True)
     tm["wall_s"] = time.perf_counter() - t_all
