@@ -21,7 +21,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 
@@ -61,11 +61,17 @@ for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     per_kernel[cname] = {k: sum(v) / len(v) * 1024.0 for k, v in acc.items()}
 
 try:
-    rd = csv.DictReader(open(one("sq/**/*counter_collection.csv")))
     acc = defaultdict(list)
-    for r in rd:
-        if "hmv::" in r["Kernel_Name"]:
-            acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for sub in ("sq", "sq2"):
+        try:
+            rd = csv.DictReader(open(one(f"{sub}/**/*counter_collection.csv")))
+        except SystemExit:
+            if sub == "sq":
+                raise
+            continue
+        for r in rd:
+            if "hmv::" in r["Kernel_Name"]:
+                acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     with open(os.path.join(dst, f"{tag}_pmc_sq.csv"), "w") as f:
         f.write("kernel,counter,mean_per_launch\n")
         for (k, c), v in sorted(acc.items()):
@@ -73,7 +79,7 @@ try:
 except SystemExit as e:
     print("no SQ pass:", e)
 
-k3 = "hmv::tf_inv_kernel<4, false>"
+k3 = "hmv::tf_inv64_asm_kernel"        # the hand-scheduled 64-channel body (round 3); "hmv::tf_inv_kernel<4, false>" before
 W = 599
 # mean bytes per launch of every kernel: FETCH_SIZE x2 (gfx950 under-count of wide streaming reads) + WRITE_SIZE
 table = {}
