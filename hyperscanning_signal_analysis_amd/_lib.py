@@ -52,6 +52,21 @@ SIGNATURES = {
     "hmv_tf_ffdtf_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "hmv_tf_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_double, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "hmv_tf_ffdtf_bands_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "hmv_tf_ffdtf_bands_f64": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                       c_void_p]),
+    "hmv_sliding_bands_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "hmv_sliding_ffdtf_bands_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                            c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double,
+                                            c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
+    "hmv_sliding_spectra_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "hmv_sliding_ffdtf_spectra_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                              c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double, c_int64, c_int64,
+                                              c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "hmv_sliding_ffdtf_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int64, c_int64, c_double, c_int64, c_int64, c_int64, c_int64,

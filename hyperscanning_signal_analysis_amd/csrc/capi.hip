@@ -181,7 +181,7 @@ int hmv_spectra_f64(const double* H, const double* V, double* Sout, int64_t n_it
   if (mp < 0) return fail(-1, "hmv_spectra_f64: channel count must be in 1..64");
   if (!H || !V || !Sout) return fail(-4, "hmv_spectra_f64: null pointer");
   hmv::SpecArgs a;
-  a.H = H; a.V = V; a.S = Sout; a.S_mmf = nullptr; a.n_items = n_items; a.F = F; a.m = m;
+  a.H = H; a.V = V; a.S = Sout; a.S_mmf = nullptr; a.n_items = n_items; a.F = F; a.m = m; a.sym = 0;
   return hmv::launch_spectra(a, mp, S(stream));
 }
 
@@ -190,7 +190,7 @@ int hmv_spectra_mmf_f64(const double* H, const double* V, double* Sout, int64_t 
   if (mp < 0) return fail(-1, "hmv_spectra_mmf_f64: channel count must be in 1..64");
   if (!H || !V || !Sout) return fail(-4, "hmv_spectra_mmf_f64: null pointer");
   hmv::SpecArgs a;
-  a.H = H; a.V = V; a.S = nullptr; a.S_mmf = Sout; a.n_items = n_items; a.F = F; a.m = m;
+  a.H = H; a.V = V; a.S = nullptr; a.S_mmf = Sout; a.n_items = n_items; a.F = F; a.m = m; a.sym = 0;
   return hmv::launch_spectra(a, mp, S(stream));
 }
 
@@ -291,9 +291,12 @@ int hmv_dpss_f64(int64_t n_times, double half_nbw, int k_max, int sym, double* t
 // ---- K3 with the ffDTF normalisation folded in ------------------------------------------------------
 namespace {
 struct TfFfWs {
-  size_t off_arx, off_P, off_rowsum, off_cnt, total;
+  size_t off_arx, off_P, off_rowsum, off_cnt, off_tail, total;
 };
-TfFfWs tf_ff_layout(int64_t n, int mp, int p, int F) {
+int64_t norm_lag_items(int mp, int F);
+// `bands`: the reduced-product form also needs the full-resolution rows of the last `lag` windows of a batch (the ones the
+// separate K4 pass normalises) for a moment, before their band sums are taken
+TfFfWs tf_ff_layout(int64_t n, int mp, int p, int F, bool bands = false) {
   TfFfWs w;
   size_t o = 0;
   const size_t t = (size_t)mp * mp;
@@ -301,6 +304,11 @@ TfFfWs tf_ff_layout(int64_t n, int mp, int p, int F) {
   w.off_P = o;      o += align256(sizeof(double) * n * F * t);
   w.off_rowsum = o; o += align256(sizeof(double) * n * F * mp);
   w.off_cnt = o;    o += align256(sizeof(int) * (2 * n + 1 + n * mp));     // wcount, ready, missed (TfArgs)
+  w.off_tail = o;
+  if (bands) {
+    const int64_t lag = norm_lag_items(mp, F);
+    o += align256(sizeof(double) * (size_t)(n < lag ? n : lag) * F * t);
+  }
   w.total = o;
   return w;
 }
@@ -323,18 +331,32 @@ int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F) {
   return (int64_t)tf_ff_layout(n_items, mp, p, F).total;
 }
 
-int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* ffdtf,
-                     double* den, double* H, int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes,
-                     int64_t flags, void* ev_k3_start, void* ev_k3_stop, void* stream) {
+namespace {
+// ffdtf != NULL: the full array.  band_out != NULL: its band sums only (see hmv_tf_ffdtf_bands_f64).
+int tf_ffdtf_impl(const char* who, const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* ffdtf,
+                  double* band_out, const int32_t* bin_lo, const int32_t* bin_hi, int n_bands, double* den, double* H,
+                  int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes, int64_t flags,
+                  void* ev_k3_start, void* ev_k3_stop, void* stream) {
+  auto failw = [&](int code, const char* msg) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "%s: %s", who, msg);
+    return fail(code, buf);
+  };
   const int mp = pad_of(m);
-  if (mp < 0) return fail(-1, "hmv_tf_ffdtf_f64: channel count must be in 1..64");
-  if (p < 1) return fail(-2, "hmv_tf_ffdtf_f64: model order must be >= 1");
+  const bool bands = (band_out != nullptr);
+  if (mp < 0) return failw(-1, "channel count must be in 1..64");
+  if (p < 1) return failw(-2, "model order must be >= 1");
   if (n_items == 0) return 0;
-  if (!ar || !tw || !ffdtf || !den || !info || !workspace || n_items < 0 || F < 1)
-    return fail(-4, "hmv_tf_ffdtf_f64: null pointer / empty grid");
-  if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return fail(-6, "hmv_tf_ffdtf_f64: pivot_tau must be in (0, 1]");
-  const TfFfWs w = tf_ff_layout(n_items, mp, p, F);
-  if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_tf_ffdtf_f64: workspace too small");
+  if (!ar || !tw || (!ffdtf && !bands) || !den || !info || !workspace || n_items < 0 || F < 1)
+    return failw(-4, "null pointer / empty grid");
+  if (!(pivot_tau > 0.0) || pivot_tau > 1.0) return failw(-6, "pivot_tau must be in (0, 1]");
+  if (bands) {
+    if (!bin_lo || !bin_hi || n_bands < 1) return failw(-4, "band bins missing");
+    if (F % 32 != 0 || F > hmv::tf_band_max_F(mp) || (flags & HMV_FLAG_UNFUSED_NORM))
+      return failw(-10, "in-kernel band sums need F % 32 == 0, F within the row worker's LDS block and the fused normalisation");
+  }
+  const TfFfWs w = tf_ff_layout(n_items, mp, p, F, bands);
+  if ((int64_t)w.total > workspace_bytes) return failw(-7, "workspace too small");
   char* base = static_cast<char*>(workspace);
   const size_t t = (size_t)mp * mp;
   hmv::TfArgs a{};
@@ -343,11 +365,15 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
   a.H = H;
   a.info = info; a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   // the in-kernel normaliser moves 16 bytes per lane: whole 16-frequency lines of a 16-byte aligned output
-  const bool fused = !(flags & HMV_FLAG_UNFUSED_NORM) && (F % 16 == 0) && (reinterpret_cast<uintptr_t>(ffdtf) % 16 == 0);
+  const bool fused = bands || (!(flags & HMV_FLAG_UNFUSED_NORM) && (F % 16 == 0) && (reinterpret_cast<uintptr_t>(ffdtf) % 16 == 0));
   const int64_t lag = norm_lag_items(mp, F);
   const int64_t n_fused = (fused && n_items > lag) ? n_items - lag : 0;
   if (n_fused > 0) {
-    a.ff = ffdtf; a.den = den; a.fuse_items = n_fused; a.lag = (int)lag;
+    a.ff = bands ? nullptr : ffdtf; a.den = den; a.fuse_items = n_fused; a.lag = (int)lag;
+    if (bands) {
+      a.bands = band_out; a.band_lo = reinterpret_cast<const int*>(bin_lo); a.band_hi = reinterpret_cast<const int*>(bin_hi);
+      a.nb = n_bands;
+    }
     a.wcount = reinterpret_cast<int*>(base + w.off_cnt);
     a.ready = a.wcount + n_items;
     a.missed = a.ready + n_items;
@@ -365,18 +391,47 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
     if (!rc) rc = erc;
   }
   if (rc) return rc;
-  if (n_fused < n_items)
+  if (n_fused < n_items) {
+    const int64_t n_tail = n_items - n_fused;
+    double* tail = bands ? reinterpret_cast<double*>(base + w.off_tail) : ffdtf + (size_t)n_fused * m * m * F;
     rc = hmv_ffdtf_norm_f64(a.P + (size_t)n_fused * F * t, a.rowsum + (size_t)n_fused * F * mp, den + (size_t)n_fused * mp,
-                            ffdtf + (size_t)n_fused * m * m * F, n_items - n_fused, F, m, 1, stream);
+                            tail, n_tail, F, m, 1, stream);
+    if (!rc && bands)
+      rc = hmv::launch_band_sums(tail, reinterpret_cast<const int*>(bin_lo), reinterpret_cast<const int*>(bin_hi),
+                                 band_out + (size_t)n_fused * m * m * n_bands, n_tail * (long long)m * m, F, n_bands, st);
+  }
   return rc;
+}
+}  // namespace
+
+int64_t hmv_tf_ffdtf_bands_workspace_bytes(int64_t n_items, int m, int p, int F) {
+  const int mp = pad_of(m);
+  if (mp < 0 || n_items < 0 || p < 1 || F < 1) return -1;
+  return (int64_t)tf_ff_layout(n_items, mp, p, F, true).total;
+}
+
+int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* ffdtf,
+                     double* den, double* H, int32_t* info, double pivot_tau, void* workspace, int64_t workspace_bytes,
+                     int64_t flags, void* ev_k3_start, void* ev_k3_stop, void* stream) {
+  return tf_ffdtf_impl("hmv_tf_ffdtf_f64", ar, n_items, m, p, tw, F, ffdtf, nullptr, nullptr, nullptr, 0, den, H, info,
+                       pivot_tau, workspace, workspace_bytes, flags, ev_k3_start, ev_k3_stop, stream);
+}
+
+int hmv_tf_ffdtf_bands_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F, double* band_out,
+                           const int32_t* bin_lo, const int32_t* bin_hi, int n_bands, double* den, int32_t* info,
+                           double pivot_tau, void* workspace, int64_t workspace_bytes, int64_t flags, void* ev_k3_start,
+                           void* ev_k3_stop, void* stream) {
+  if (!band_out) return fail(-4, "hmv_tf_ffdtf_bands_f64: null pointer / empty grid");
+  return tf_ffdtf_impl("hmv_tf_ffdtf_bands_f64", ar, n_items, m, p, tw, F, nullptr, band_out, bin_lo, bin_hi, n_bands, den,
+                       nullptr, info, pivot_tau, workspace, workspace_bytes, flags, ev_k3_start, ev_k3_stop, stream);
 }
 
 // ---- fused sliding-window path ----------------------------------------------------------------------
 namespace {
 struct SlidingWs {
-  size_t off_R, off_Q, off_ws, off_ar, off_V, off_tf, off_den, off_tw, total;
+  size_t off_R, off_Q, off_ws, off_ar, off_V, off_tf, off_den, off_tw, off_H, total;
 };
-SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
+SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F, bool bands = false, bool spectra = false) {
   SlidingWs w;
   size_t o = 0;
   const size_t t = (size_t)mp * mp;
@@ -385,9 +440,11 @@ SlidingWs sliding_layout(int64_t chunk, int mp, int p, int F) {
   w.off_ws = o;     o += align256(sizeof(double) * chunk * hmv::yw_ws_tiles(p) * t);
   w.off_ar = o;     o += align256(sizeof(double) * chunk * t * p);
   w.off_V = o;      o += align256(sizeof(double) * chunk * t);
-  w.off_tf = o;     o += tf_ff_layout(chunk, mp, p, F).total;
+  w.off_tf = o;     o += tf_ff_layout(chunk, mp, p, F, bands).total;
   w.off_den = o;    o += align256(sizeof(double) * chunk * mp);
   w.off_tw = o;     o += align256(sizeof(double) * F * p * 2);
+  w.off_H = o;
+  if (spectra) o += align256(sizeof(double) * 2 * chunk * F * t);       // H (complex) of one chunk, between K3 and K5
   w.total = o;
   return w;
 }
@@ -415,21 +472,29 @@ int64_t hmv_sliding_workspace_bytes(int64_t chunk, int m, int p, int F) {
   return (int64_t)sliding_layout(chunk, mp, p, F).total;
 }
 
-int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
-                          const int64_t* item_start, int64_t n_items, int m, int n, int p,
-                          const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
-                          int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
-                          int64_t chunk, double pivot_tau, int64_t flags, int64_t grid_hop, int64_t grid_first,
-                          int64_t grid_nwin, int64_t grid_T, void* ev_k3_start, void* ev_k3_stop, void* stream,
-                          void* aux_stream) {
+namespace {
+int sliding_impl(const char* who, const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                 const int64_t* item_start, int64_t n_items, int m, int n, int p, const double* freqs, int F, double fs,
+                 double* ffdtf, double* band_out, const int32_t* bin_lo, const int32_t* bin_hi, int n_bands, double* S_out,
+                 double* ar_out, double* V_out, int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes, int64_t chunk,
+                 double pivot_tau, int64_t flags, int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T,
+                 void* ev_k3_start, void* ev_k3_stop, void* stream, void* aux_stream) {
+  const bool bands = (band_out != nullptr);
+  auto fail = [&](int code, const char* msg) {
+    const char* own = strchr(msg, ':');             // messages below are written "hmv_sliding_ffdtf_f64: ..."
+    char buf[220];
+    snprintf(buf, sizeof(buf), "%s%s", who, own ? own : msg);
+    return ::fail(code, buf);
+  };
   const int mp = pad_of(m);
   if (mp < 0) return fail(-1, "hmv_sliding_ffdtf_f64: channel count must be in 1..64");
   if (p < 1 || p > HMV_MAX_ORDER) return fail(-2, "hmv_sliding_ffdtf_f64: model order must be in 1..32");
   if (n <= p) return fail(-3, "hmv_sliding_ffdtf_f64: window shorter than the model order");
   if (n_items == 0) return 0;                                    // empty batch: nothing to do, nothing to check
-  if (!x || !item_rec || !item_start || !freqs || !ffdtf || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
+  if (!x || !item_rec || !item_start || !freqs || (!ffdtf && !bands) || !info_yw || !info_tf || !workspace || F < 1 || chunk < 1)
     return fail(-4, "hmv_sliding_ffdtf_f64: null pointer / empty grid");
-  const SlidingWs w = sliding_layout(chunk, mp, p, F);
+  if (bands && (!bin_lo || !bin_hi || n_bands < 1)) return fail(-4, "hmv_sliding_ffdtf_f64: band bins missing");
+  const SlidingWs w = sliding_layout(chunk, mp, p, F, bands, S_out != nullptr);
   if ((int64_t)w.total > workspace_bytes) return fail(-7, "hmv_sliding_ffdtf_f64: workspace too small");
   // Regular grid (the caller vouches: item = rec * grid_nwin + w starts at grid_first + w * grid_hop of recording rec,
   // recordings are grid_T samples long): K1 sums every hop block once and assembles the windows from the blocks.
@@ -464,7 +529,7 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
   void* tfws = base + w.off_tf;
   double* den = reinterpret_cast<double*>(base + w.off_den);
   double* tw = reinterpret_cast<double*>(base + w.off_tw);
-  const int64_t tfws_bytes = (int64_t)tf_ff_layout(chunk, mp, p, F).total;
+  const int64_t tfws_bytes = (int64_t)tf_ff_layout(chunk, mp, p, F, bands).total;
   rc = hmv_twiddles_f64(freqs, F, fs, p, tw, st0);
   const size_t ws_item = (size_t)hmv_yw_workspace_doubles(m, p);
   for (int64_t ci = 0; ci < n_chunks && rc == 0; ++ci) {
@@ -512,10 +577,73 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const
     rc = hmv_yw_solve_f64(R, c0, m, p, ws, ar_c, V_c, nullptr, info_yw + i0, yw_flags, st0);
     if (rc) break;
     const bool last = (ci == n_chunks - 1);
-    rc = hmv_tf_ffdtf_f64(ar_c, c, m, p, tw, F, ffdtf + (size_t)i0 * m * m * F, den, nullptr, info_tf + (size_t)i0 * F, pivot_tau,
-                          tfws, tfws_bytes, flags, last ? ev_k3_start : nullptr, last ? ev_k3_stop : nullptr, st0);
+    double* Hc = S_out ? reinterpret_cast<double*>(base + w.off_H) : nullptr;
+    rc = tf_ffdtf_impl(who, ar_c, c, m, p, tw, F, bands ? nullptr : ffdtf + (size_t)i0 * m * m * F,
+                       bands ? band_out + (size_t)i0 * m * m * n_bands : nullptr, bin_lo, bin_hi, n_bands, den, Hc,
+                       info_tf + (size_t)i0 * F, pivot_tau, tfws, tfws_bytes, flags, last ? ev_k3_start : nullptr,
+                       last ? ev_k3_stop : nullptr, st0);
+    if (!rc && S_out) {      // K5 from the same inverses and the same fit; V is this library's own (symmetric) estimate
+      hmv::SpecArgs sa;
+      sa.H = Hc; sa.V = V_c; sa.S = nullptr; sa.S_mmf = S_out + (size_t)i0 * m * m * F * 2; sa.n_items = c; sa.F = F; sa.m = m;
+      sa.sym = 1;
+      rc = hmv::launch_spectra(sa, mp, st0);
+    }
   }
   return rc;
+}
+}  // namespace
+
+int64_t hmv_sliding_bands_workspace_bytes(int64_t chunk, int m, int p, int F) {
+  const int mp = pad_of(m);
+  if (mp < 0 || chunk < 1 || p < 1 || p > HMV_MAX_ORDER || F < 1) return -1;
+  return (int64_t)sliding_layout(chunk, mp, p, F, true).total;
+}
+
+int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                          const int64_t* item_start, int64_t n_items, int m, int n, int p,
+                          const double* freqs, int F, double fs, double* ffdtf, double* ar_out, double* V_out,
+                          int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
+                          int64_t chunk, double pivot_tau, int64_t flags, int64_t grid_hop, int64_t grid_first,
+                          int64_t grid_nwin, int64_t grid_T, void* ev_k3_start, void* ev_k3_stop, void* stream,
+                          void* aux_stream) {
+  return sliding_impl("hmv_sliding_ffdtf_f64", x, rec_stride, ld, item_rec, item_start, n_items, m, n, p, freqs, F, fs, ffdtf,
+                      nullptr, nullptr, nullptr, 0, nullptr, ar_out, V_out, info_yw, info_tf, workspace, workspace_bytes, chunk,
+                      pivot_tau, flags, grid_hop, grid_first, grid_nwin, grid_T, ev_k3_start, ev_k3_stop, stream, aux_stream);
+}
+
+int hmv_sliding_ffdtf_bands_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                                const int64_t* item_start, int64_t n_items, int m, int n, int p,
+                                const double* freqs, int F, double fs, double* band_out, const int32_t* bin_lo,
+                                const int32_t* bin_hi, int n_bands, double* ar_out, double* V_out,
+                                int32_t* info_yw, int32_t* info_tf, void* workspace, int64_t workspace_bytes,
+                                int64_t chunk, double pivot_tau, int64_t flags, int64_t grid_hop, int64_t grid_first,
+                                int64_t grid_nwin, int64_t grid_T, void* ev_k3_start, void* ev_k3_stop, void* stream,
+                                void* aux_stream) {
+  if (!band_out && n_items != 0) return fail(-4, "hmv_sliding_ffdtf_bands_f64: null pointer / empty grid");
+  return sliding_impl("hmv_sliding_ffdtf_bands_f64", x, rec_stride, ld, item_rec, item_start, n_items, m, n, p, freqs, F, fs,
+                      nullptr, band_out, bin_lo, bin_hi, n_bands, nullptr, ar_out, V_out, info_yw, info_tf, workspace,
+                      workspace_bytes, chunk, pivot_tau, flags, grid_hop, grid_first, grid_nwin, grid_T, ev_k3_start, ev_k3_stop,
+                      stream, aux_stream);
+}
+
+int64_t hmv_sliding_spectra_workspace_bytes(int64_t chunk, int m, int p, int F) {
+  const int mp = pad_of(m);
+  if (mp < 0 || chunk < 1 || p < 1 || p > HMV_MAX_ORDER || F < 1) return -1;
+  return (int64_t)sliding_layout(chunk, mp, p, F, false, true).total;
+}
+
+int hmv_sliding_ffdtf_spectra_f64(const double* x, int64_t rec_stride, int64_t ld, const int64_t* item_rec,
+                                  const int64_t* item_start, int64_t n_items, int m, int n, int p,
+                                  const double* freqs, int F, double fs, double* ffdtf, double* S_out, double* ar_out,
+                                  double* V_out, int32_t* info_yw, int32_t* info_tf, void* workspace,
+                                  int64_t workspace_bytes, int64_t chunk, double pivot_tau, int64_t flags,
+                                  int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T, void* stream,
+                                  void* aux_stream) {
+  if (!S_out && n_items != 0) return fail(-4, "hmv_sliding_ffdtf_spectra_f64: null pointer / empty grid");
+  return sliding_impl("hmv_sliding_ffdtf_spectra_f64", x, rec_stride, ld, item_rec, item_start, n_items, m, n, p, freqs, F,
+                      fs, ffdtf, nullptr, nullptr, nullptr, 0, S_out, ar_out, V_out, info_yw, info_tf, workspace,
+                      workspace_bytes, chunk, pivot_tau, flags, grid_hop, grid_first, grid_nwin, grid_T, nullptr, nullptr,
+                      stream, aux_stream);
 }
 
 }  // extern "C"

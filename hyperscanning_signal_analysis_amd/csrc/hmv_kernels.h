@@ -80,12 +80,20 @@ struct TfArgs {
   int* missed;              // [1 + fuse_items * MP] count, rows     } of rows left to norm_missed_kernel
   long long fuse_items;
   int lag;
+  // reduced product (hot path, in-kernel normalisation only; bands == nullptr: off): instead of the ffDTF array the row
+  // workers write its band sums, bands[item][i][j][b] = sum_{band_lo[b] <= f < band_hi[b]} ffdtf[item][i][j][f]
+  // (the arithmetic of band_sums_stream_kernel, ffdtf_norm.hip: same partial sums, same tree, same bits); ff is unused
+  double* bands;            // [n_items][m][m][nb]
+  const int* band_lo;       // [nb] device
+  const int* band_hi;       // [nb] device
+  int nb;
   unsigned long long* stamps;   // diagnostic builds (-DHMV_STAMP) only: [wave][8] phase cycle sums; else null
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
 int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);
 int launch_cinv(const TfArgs& a, int m_pad, hipStream_t st);
 long long tf_workspace_doubles(long long n_items, int m_pad, int p);
+int tf_band_max_F(int m_pad);
 
 // ---- K4 ffDTF normalisation + layout transposes -------------------------------------------------
 struct NormArgs {
@@ -115,6 +123,7 @@ struct SpecArgs {
   double* S_mmf;            // complex [n_items][m][m][F], the reference's array layout, written by the kernel itself
   long long n_items;
   int F, m;
+  int sym;                  // 1: V is symmetric (this library's own fit) -- with S_mmf only the upper triangle is computed
 };
 int launch_spectra(const SpecArgs& a, int m_pad, hipStream_t st);
 

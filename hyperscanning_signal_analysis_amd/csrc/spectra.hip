@@ -20,8 +20,26 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 //   stage 2, S = T H^T:   per quarter  A0/A1 = Tr/Ti[:, kq] (own row strip, from registers), B0/B1 = Re/Im H[:, kq]
 //                                      Sr += A0 B0^T - A1 B1^T,  Si += A0 B1^T + A1 B0^T
 // k ascends 0 .. MP-1 in every sum, as in the round-1 kernel: same bits.
+// Symmetric V (the residual covariance of this library's own fit): S = H V H^T is complex SYMMETRIC, so stage 2 only
+// computes the 4-row x 16-column units (r4, J) that touch the upper triangle, r4 <= 4 J + 3 -- 2 NT (NT + 1) of the
+// 4 NT^2 units, 40 of 64 at 64 channels -- and every element above the diagonal is written to both places.  The units
+// are dealt to the FOUR waves of the workgroup in contiguous runs of NT (NT + 1) / 2 (J descending, r4 ascending): every
+// wave the same number of MFMAs, its A operands from any row strip of the T images (all in LDS), one or two distinct B
+// column blocks.
 template <int NT>
-__global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
+struct SymDeal {
+  static constexpr int U = NT * (NT + 1) / 2;              // units per wave (4 waves whatever NT is)
+  static constexpr int J_of(int g) { int J = NT - 1; while (g >= 4 * (J + 1)) { g -= 4 * (J + 1); --J; } return J; }
+  static constexpr int r4_of(int g) { int J = NT - 1; while (g >= 4 * (J + 1)) { g -= 4 * (J + 1); --J; } return g; }
+};
+
+// Workgroups per CU of the symmetric form: its 40 (instead of 64) accumulators would let three fit, but only with 34
+// spilled registers (168 VGPRs): measured 26.9 k windows/s (ffDTF + spectra, C2) against 28.4 k with two (same box)
+#ifndef HMV_K5_SYM_WGS
+#define HMV_K5_SYM_WGS 2
+#endif
+template <int NT, bool SYM>
+__global__ void __launch_bounds__(256, SYM ? HMV_K5_SYM_WGS : 2) spectra_kernel(SpecArgs a) {
   constexpr int MP = 16 * NT, NIW = NT, NJ = NT, KQ = MP / 4, SQ = KQ + 6, TILE = MP * MP;
   constexpr int NH = (MP * KQ + 255) / 256;          // complex elements of an H quarter per thread
   constexpr int NVV = (MP * KQ / 2 + 255) / 256;     // 16-byte loads of a V quarter per thread
@@ -144,6 +162,56 @@ __global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
     gemm_q(tr, A0, B0, false);                     // Tr += Hr V
     gemm_q(ti, A1, B0, false);                     // Ti += Hi V
   }
+  if constexpr (SYM) {                             // ---- stage 2, upper triangle only
+    using D = SymDeal<NT>;
+    auto stage2 = [&](auto wc) __attribute__((always_inline)) {
+      constexpr int W = decltype(wc)::value;
+      double ur[D::U], ui[D::U];
+#pragma unroll
+      for (int u = 0; u < D::U; ++u) ur[u] = ui[u] = 0.0;
+      for (int kq = 0; kq < 4; ++kq) {
+        __syncthreads();
+        park_strip(A0, tr, kq);
+        park_strip(A1, ti, kq);
+        park_h(B0, B1, hv);
+        if (kq < 3) fetch_h(hv, kq + 1);
+        __syncthreads();
+        const int l = lane();
+        const int ao = (l & 3) * SQ + (l >> 4), bo = (l & 15) * SQ + (l >> 4);
+#pragma unroll
+        for (int k0 = 0; k0 < KQ; k0 += 4) {
+          static_for<D::U>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value, g = W * D::U + u, r4 = D::r4_of(g), J = D::J_of(g);
+            const double a0 = A0[ao + 4 * r4 * SQ + k0], a1 = A1[ao + 4 * r4 * SQ + k0];
+            const double b0 = B0[bo + 16 * J * SQ + k0], b1 = B1[bo + 16 * J * SQ + k0];
+            ur[u] = mfma4(a0, b0, ur[u]);          // Tr Hr^T
+            ur[u] = mfma4_nega(a1, b1, ur[u]);     // - Ti Hi^T
+            ui[u] = mfma4(a0, b1, ui[u]);          // Tr Hi^T
+            ui[u] = mfma4(a1, b0, ui[u]);          // + Ti Hr^T
+          });
+        }
+      }
+      const int l = lane(), i = l >> 4, cc = l & 15;
+      const int m = a.m, f = (int)(gw - item * a.F);
+      double2* So = reinterpret_cast<double2*>(a.S_mmf) + (size_t)item * m * m * a.F + f;
+      static_for<D::U>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, g = W * D::U + u, r4 = D::r4_of(g), J = D::J_of(g);
+        const int row = 4 * r4 + i, col = 16 * J + cc;
+        if (row <= col && col < m) {
+          const double2 v = make_double2(ur[u], ui[u]);
+          So[((size_t)row * m + col) * a.F] = v;
+          if (row < col) So[((size_t)col * m + row) * a.F] = v;
+        }
+      });
+    };
+    switch (wv) {
+      case 0: stage2(std::integral_constant<int, 0>{}); break;
+      case 1: stage2(std::integral_constant<int, 1>{}); break;
+      case 2: stage2(std::integral_constant<int, 2>{}); break;
+      default: stage2(std::integral_constant<int, 3>{}); break;
+    }
+    return;
+  } else {
   double sr[NIW][NJ], si[NIW][NJ];
 #pragma unroll
   for (int ii = 0; ii < NIW; ++ii)
@@ -180,17 +248,28 @@ __global__ void __launch_bounds__(256, 2) spectra_kernel(SpecArgs a) {
 #pragma unroll
     for (int J = 0; J < NJ; ++J)
       So[(size_t)(4 * (wv * NT + ii) + i) * MP + 16 * J + cc] = make_double2(sr[ii][J], si[ii][J]);
+  }
 }
 
 int launch_spectra(const SpecArgs& a, int m_pad, hipStream_t st) {
   const long long n = a.n_items * (long long)a.F;
   if (n == 0) return 0;
   const dim3 grid((unsigned)n), block(256);
+  if (a.sym && a.S_mmf) {
+    switch (m_pad) {
+      case 16: hipLaunchKernelGGL((spectra_kernel<1, true>), grid, block, 0, st, a); break;
+      case 32: hipLaunchKernelGGL((spectra_kernel<2, true>), grid, block, 0, st, a); break;
+      case 48: hipLaunchKernelGGL((spectra_kernel<3, true>), grid, block, 0, st, a); break;
+      case 64: hipLaunchKernelGGL((spectra_kernel<4, true>), grid, block, 0, st, a); break;
+      default: return -1;
+    }
+    return (int)hipGetLastError();
+  }
   switch (m_pad) {
-    case 16: hipLaunchKernelGGL(spectra_kernel<1>, grid, block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL(spectra_kernel<2>, grid, block, 0, st, a); break;
-    case 48: hipLaunchKernelGGL(spectra_kernel<3>, grid, block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL(spectra_kernel<4>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((spectra_kernel<1, false>), grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((spectra_kernel<2, false>), grid, block, 0, st, a); break;
+    case 48: hipLaunchKernelGGL((spectra_kernel<3, false>), grid, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((spectra_kernel<4, false>), grid, block, 0, st, a); break;
     default: return -1;
   }
   return (int)hipGetLastError();

@@ -245,15 +245,94 @@ __device__ __forceinline__ void normalise_row(const TfArgs& a, int item, int i, 
   }
 }
 
+// Reduced product: the band sums of output row i of window `item` instead of the row itself,
+//     bands[item][i][j][b] = sum_{lo[b] <= f < hi[b]} |H_ij(f)|^2 * (1 / den[i]),
+// for callers that integrate ffDTF over frequency bands anyway (the reference's graph plots, mtmvar.py:984-987; the
+// product that crosses PCIe / xGMI, distributed.py) -- the 8.4 MB per window of the full array are then never written.
+// Same arithmetic as band_sums_stream_kernel (ffdtf_norm.hip) on the array normalise_row would have written: lane c of
+// a 16-lane row owns the frequency pairs (32 k + 2 c, 32 k + 2 c + 1), k ascending, every value first rounded to the
+// ffDTF element (x * r), added through 0 / 1 weights by FMA, then one 16-lane DPP tree -- the same bits, which the
+// tests compare.  A wave covers 8 columns per trip (two per lane: the kernel lives in 96 VGPRs), the workgroup MP / 2,
+// so the slab Pp[item][i][f][j] is read in two column halves, once per pass of NBP bands.  The weight table lives in
+// `lds` (`lds_doubles` of it, >= F): built here from the bin ranges.  Every thread of the workgroup; F % 32 == 0.
+template <int NT>
+__device__ __forceinline__ void band_row(const TfArgs& a, int item, int i, double* lds, const int lds_doubles, const int tid) {
+  constexpr int MP = 16 * NT, NBP = 5, D = 4;
+  const int F = a.F, m = a.m, nb = a.nb;
+  const int l = tid & 63, wv = uni(tid >> 6);
+  const int c = l & 15, jl = 8 * wv + 2 * (l >> 4);        // this lane's columns: jl, jl + 1 (+ MP / 2 in the second half)
+  const double r = 1.0 / __hip_atomic_load(a.den + (size_t)item * MP + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int fit = lds_doubles / F;
+  const int nbp = fit < NBP ? fit : NBP;                   // bands per pass (the launcher checked fit >= 1)
+  const int nk = F >> 5;
+  for (int b0 = 0; b0 < nb; b0 += nbp) {
+    __syncthreads();                                       // the previous pass's table has been read
+    for (int e = tid; e < nbp * F; e += 64 * NT) {
+      const int b = e / F, f = e - b * F, bb = b0 + b;
+      lds[e] = (bb < nb && f >= a.band_lo[bb] && f < a.band_hi[bb]) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const double* wl = lds + 2 * c;
+#pragma unroll 1
+    for (int jh = 0; jh < 2; ++jh) {
+      const int j0 = jl + jh * (MP / 2);
+      const double* Pw = a.P + ((size_t)item * MP + i) * F * MP + (size_t)(2 * c) * MP + j0;     // Pp[item][i][2c][j0]
+      double acc[NBP][2];
+#pragma unroll
+      for (int b = 0; b < NBP; ++b) acc[b][0] = acc[b][1] = 0.0;
+      auto issue = [&](f64x2 (&v)[2], int k) __attribute__((always_inline)) {
+        if (k < nk) {
+          const double* src = Pw + (size_t)(32 * k) * MP;
+          v[0] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src));          // frequency 32 k + 2 c
+          v[1] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src + MP));     // frequency 32 k + 2 c + 1
+        }
+      };
+      auto drain = [&](const f64x2 (&v)[2], int k) __attribute__((always_inline)) {
+        if (k < nk) {
+          const double x0[2] = {v[0].x * r, v[0].y * r}, x1[2] = {v[1].x * r, v[1].y * r};
+#pragma unroll
+          for (int b = 0; b < NBP; ++b) {
+            if (b < nbp) {
+              const f64x2 w = *reinterpret_cast<const f64x2*>(wl + b * F + 32 * k);
+              acc[b][0] = __builtin_fma(x1[0], w.y, __builtin_fma(x0[0], w.x, acc[b][0]));
+              acc[b][1] = __builtin_fma(x1[1], w.y, __builtin_fma(x0[1], w.x, acc[b][1]));
+            }
+          }
+        }
+      };
+      f64x2 buf[D][2];
+      static_for<D>([&](auto dc) __attribute__((always_inline)) { issue(buf[decltype(dc)::value], decltype(dc)::value); });
+      for (int k = 0; k < nk; k += D) {
+        static_for<D>([&](auto dc) __attribute__((always_inline)) {
+          constexpr int d = decltype(dc)::value;
+          drain(buf[d], k + d);
+          issue(buf[d], k + d + D);
+        });
+      }
+      double* ow = a.bands + (((size_t)item * m + i) * m + j0) * nb + b0;
+#pragma unroll
+      for (int b = 0; b < NBP; ++b) {
+        if (b < nbp && b0 + b < nb) {
+          const double t0 = row16_sum_dpp(acc[b][0]), t1 = row16_sum_dpp(acc[b][1]);
+          if (c == 0 && j0 < m) ow[b] = t0;
+          if (c == 0 && j0 + 1 < m) ow[nb + b] = t1;
+        }
+      }
+    }
+  }
+}
+
 // Rows that found their window unfinished inside K3 (a.missed[0] = how many, a.missed[1..] = item * MP + i).  Runs
 // after K3 on the same stream, so everything is visible; normally the list is empty.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
-  __shared__ double lds[NormLds<NT>::DOUBLES];
+  __shared__ double lds[2 * TfLds<NT>::TOTAL];           // as much as the row workers inside K3 have
+  static_assert(NormLds<NT>::DOUBLES <= 2 * TfLds<NT>::TOTAL, "normaliser tiles do not fit");
   const int n = a.missed[0];
   for (int k = blockIdx.x; k < n; k += gridDim.x) {
     const int e = a.missed[1 + k];
-    normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, (int)threadIdx.x);
+    if (a.bands) band_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, 2 * TfLds<NT>::TOTAL, (int)threadIdx.x);
+    else normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, (int)threadIdx.x);
     __syncthreads();
   }
 }
@@ -263,7 +342,10 @@ __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
 // H / |H|^2 / row sums, the write-through publish and the in-kernel ffDTF normalisation.  `smem` is the inversion's
 // LDS block (free after the last barrier of the inversion), `rsum` NT * MP doubles inside it that the publish tile does
 // not cover, `s_orig` the column permutation left by the row interchanges, `s_flag` one int of LDS.
-template <int NT, bool GEN>
+// BANDS: the reduced-product row worker (band_row) is compiled in.  Off for the compiler-scheduled 64-channel kernel only:
+// the launcher sends band-sum launches of that shape to the hand-scheduled body, and the extra code costs the
+// compiler-scheduled one ~100 spilled registers.
+template <int NT, bool GEN, bool BANDS = true>
 __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, const int f, const long long gw, const int w,
                                            const int wv, double (&re)[NT][4], double (&im)[NT][4], double2* smem,
                                            double* rsum, const int* s_orig, int* s_flag, const double* s_det
@@ -306,7 +388,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
   }
   if (a.P) {
     double* rs = rsum + w * MP + rowo;
-    const bool publish = !GEN && a.ff != nullptr && item < a.fuse_items;     // workgroup-uniform
+    const bool publish = !GEN && (a.ff != nullptr || a.bands != nullptr) && item < a.fuse_items;     // workgroup-uniform
     if (!publish) {
       double* Po = a.P + (size_t)gw * MP * MP + (size_t)rowo * MP;
 #pragma unroll
@@ -379,7 +461,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
   // count completes the window (agent-scope acquire: its CU's L1 is invalidated) adds up the denominators and
   // raises ready[window].  Nobody waits for anybody.
   if constexpr (!GEN) {
-    if (a.ff != nullptr) {                                   // kernel-uniform
+    if (a.ff != nullptr || a.bands != nullptr) {             // kernel-uniform
       static_assert(NormLds<NT>::DOUBLES <= 2 * L::TOTAL, "normaliser tiles do not fit the inversion's LDS block");
       double* nlds = reinterpret_cast<double*>(smem);
       if (item < a.fuse_items) {                             // workgroup-uniform
@@ -424,7 +506,12 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
         __syncthreads();
         HMV_T(6);    // denominators (rarely), flag of the window whose row is this workgroup's
         if (s_info != 0) {
-          for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds, tid);
+          if (BANDS && a.bands) {
+            if constexpr (BANDS)
+              for (int i = f; i < a.m; i += a.F) band_row<NT>(a, wl, i, nlds, 2 * L::TOTAL, tid);
+          } else {
+            for (int i = f; i < a.m; i += a.F) normalise_row<NT>(a, wl, i, nlds, tid);
+          }
         }
       }
     }
@@ -864,7 +951,7 @@ __global__ void __launch_bounds__(64 * NT, (NT == 4) ? HMV_K3_WGS : 2) tf_inv_ke
   });
 
   HMV_T(3);
-  tf_outputs<NT, GEN>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, &s_info, s_det
+  tf_outputs<NT, GEN, (NT < 4)>(a, item, f, gw, w, wv, re, im, smem, rsum, s_orig, &s_info, s_det
 #ifdef HMV_STAMP
                       , tsum, tlast
 #endif
@@ -1000,6 +1087,17 @@ int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hi
   return (int)hipGetLastError();
 }
 
+// largest frequency grid the in-kernel band sums take: one band's 0 / 1 weights must fit the row worker's LDS block
+int tf_band_max_F(int m_pad) {
+  switch (m_pad) {
+    case 16: return (2 * TfLds<1>::TOTAL) & ~31;
+    case 32: return (2 * TfLds<2>::TOTAL) & ~31;
+    case 48: return (2 * TfLds<3>::TOTAL) & ~31;
+    case 64: return (2 * TfLds<4>::TOTAL) & ~31;
+  }
+  return 0;
+}
+
 long long tf_workspace_doubles(long long n_items, int m_pad, int p) {
   return n_items * (long long)m_pad * m_pad * 2 * ((p + 1) / 2);
 }
@@ -1007,13 +1105,15 @@ long long tf_workspace_doubles(long long n_items, int m_pad, int p) {
 int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
   TfArgs a = a_in;
   if (a.n_items == 0 || a.F == 0) return 0;
-  const bool fused = (a.ff != nullptr && a.fuse_items > 0);
+  const bool fused = ((a.ff != nullptr || a.bands != nullptr) && a.fuse_items > 0);
   if (fused) {
     if (!a.P || !a.den || !a.wcount || !a.ready || !a.missed || a.lag < 1) return -3;
+    if (a.bands && (!a.band_lo || !a.band_hi || a.nb < 1 || a.F % 32 != 0 || a.F > tf_band_max_F(m_pad) || a.A)) return -3;
     // wcount, ready and missed[0] are one zeroed block (capi.hip lays them out back to back)
     if (const hipError_t e = hipMemsetAsync(a.wcount, 0, sizeof(int) * (2 * (size_t)a.n_items + 1), st)) return (int)e;
   } else {
     a.ff = nullptr;
+    a.bands = nullptr;
   }
   const long long n = a.n_items * (long long)a.F;
   const dim3 grid((unsigned)n);
@@ -1042,7 +1142,7 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tuning(5));
       }
       // the hand-scheduled body has no A(f) output (asked for by the staged API only)
-      if (tuning(3 /* HMV_TUNE_K3_FORM */) != 1 && a.A == nullptr)
+      if ((tuning(3 /* HMV_TUNE_K3_FORM */) != 1 || a.bands != nullptr) && a.A == nullptr)
         hipLaunchKernelGGL(tf_inv64_asm_kernel, grid, dim3(256), (unsigned)tuning(5 /* HMV_TUNE_K3_LDS_PAD */), st, a);
       else
         hipLaunchKernelGGL((tf_inv_kernel<4, false>), grid, dim3(256), (unsigned)tuning(5), st, a);
@@ -1065,6 +1165,7 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
 int launch_cinv(const TfArgs& a_in, int m_pad, hipStream_t st) {
   TfArgs a = a_in;
   a.ff = nullptr;
+  a.bands = nullptr;
   a.fuse_items = 0;
   const long long n = a.n_items * (long long)a.F;
   if (n == 0) return 0;

@@ -286,12 +286,10 @@ class Engine:
         _lib.check(rc, "hmv_ddtf_f64")
         return out
 
-    def band_sums(self, ff: torch.Tensor, bin_lo, bin_hi):
-        """(..., F) -> (..., n_bands): sums over the bin ranges [bin_lo[b], bin_hi[b])."""
-        F = ff.shape[-1]
-        ff = ff.contiguous()
+    def band_tables(self, bin_lo, bin_hi, F: int):
+        """Device copies (int32) of the bin ranges [bin_lo[b], bin_hi[b]) of a band set on an F-point grid, cached."""
         lo_h, hi_h = np.asarray(bin_lo, dtype=np.int32), np.asarray(bin_hi, dtype=np.int32)
-        if (lo_h < 0).any() or (hi_h > F).any() or (hi_h < lo_h).any() or lo_h.shape != hi_h.shape:
+        if (lo_h < 0).any() or (hi_h > F).any() or (hi_h < lo_h).any() or lo_h.shape != hi_h.shape or lo_h.ndim != 1:
             raise ValueError("band bin ranges must satisfy 0 <= lo <= hi <= F")
         # the bin tables live on the device per distinct band set: a fresh pageable-memory copy per call is a synchronous
         # copy on the compute stream, i.e. a host wait for everything queued before it (the streamed path's stall)
@@ -301,7 +299,18 @@ class Engine:
             if len(cache) >= 16:
                 cache.pop(next(iter(cache)))
             cache[key] = (torch.as_tensor(lo_h).to(self.device), torch.as_tensor(hi_h).to(self.device))
-        lo, hi = cache[key]
+        return cache[key]
+
+    def bands_in_kernel(self, m: int, F: int) -> bool:
+        """Can K3's row workers add up the bands themselves (`sliding_ffdtf(bands=...)` without the full array)?"""
+        cap = {16: 640, 32: 1280, 48: 1984, 64: 2688}[self.pad(m)]     # doubles of LDS the row worker has, whole 32s
+        return F % 32 == 0 and F <= cap
+
+    def band_sums(self, ff: torch.Tensor, bin_lo, bin_hi):
+        """(..., F) -> (..., n_bands): sums over the bin ranges [bin_lo[b], bin_hi[b])."""
+        F = ff.shape[-1]
+        ff = ff.contiguous()
+        lo, hi = self.band_tables(bin_lo, bin_hi, F)
         nb = int(lo.numel())
         rows = ff.numel() // F if F else 0
         out = self.empty(*ff.shape[:-1], nb)
@@ -328,6 +337,16 @@ class Engine:
         want = n_items
         return max(1, min(want, cap))
 
+    def copy_streams(self):
+        """The upload and the download stream of `stream_dyads`, created ONCE per engine.  HIP streams share a handful of
+        hardware queues (four by default) and two streams on one queue run one after the other: with fresh streams per
+        call the download of recording d and the upload of recording d + 1 ended up on the compute stream's queue and
+        the whole pipeline ran serially (device timeline, `tools/dbg/e2e_depth.py`: compute -> download -> upload ->
+        compute, 12.2 ms per dyad instead of 10.4).  High priority: their own queues, apart from the compute streams'."""
+        if "_copy" not in self.__dict__:
+            self._copy = (torch.cuda.Stream(self.device, priority=-1), torch.cuda.Stream(self.device, priority=-1))
+        return self._copy
+
     def aux_stream(self):
         """Second stream of the fused call (the tiled form of K2 runs as two half-batches), one per calling stream."""
         key = self.stream()
@@ -338,7 +357,7 @@ class Engine:
     def sliding_ffdtf(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
                       freqs, fs: float, out: torch.Tensor | None = None, return_ar: bool = False,
                       check: bool = True, chunk: int | None = None, k3_events=None, overlap: bool = True,
-                      flags: int = 0, grid=None, validate: bool = True):
+                      flags: int = 0, grid=None, validate: bool = True, bands=None):
         """ffDTF of every window: x (n_rec, m, T) -> (items, m, m, F).  One C-ABI call (K1->K2->K3->K4).
 
         check: True raises numpy.linalg.LinAlgError("Singular matrix") if ANY window failed, like the reference's
@@ -356,6 +375,11 @@ class Engine:
         the direct form to rounding, not bitwise -- `_lib.FLAG_DIRECT_LAGCOV` keeps the direct form).
         k3_events: optional pair of raw hipEvent_t handles (`torch.cuda.Event.cuda_event` of events that
         have been recorded once) which the library records around the dominant kernel.
+        bands: (bin_lo, bin_hi) -- the REDUCED product: instead of the (items, m, m, F) array the call returns its band
+        sums (items, m, m, n_bands), band b = sum over the bins bin_lo[b] <= f < bin_hi[b] (`distributed.band_bins`).
+        The row workers inside K3 add them up and the full array is never written (`hmv_sliding_ffdtf_bands_f64`); the
+        same bits as `band_sums(sliding_ffdtf(...))`, which is also what runs when the grid does not suit the kernel
+        (`bands_in_kernel`).  `out`, if given, is the band array.
         """
         assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
         x = x if x.stride(2) == 1 else x.contiguous()
@@ -371,11 +395,28 @@ class Engine:
             if return_ar:
                 return empty, self.empty(0, mp, mp, p), self.empty(0, mp, mp), (self.empty(0, dtype=torch.int32),) * 2
             return empty
+        band_out = None
+        if bands is not None:
+            b_lo, b_hi = self.band_tables(bands[0], bands[1], F)
+            nb = int(b_lo.numel())
+            if nb == 0 or not self.bands_in_kernel(m, F) or (flags & _lib.FLAG_UNFUSED_NORM):
+                # two calls: the full array (scratch), then its band sums
+                res = self.sliding_ffdtf(x, item_rec, item_start, n, p, f, fs, return_ar=return_ar, check=check, chunk=chunk,
+                                         k3_events=k3_events, overlap=overlap, flags=flags, grid=grid, validate=False)
+                full = res[0] if isinstance(res, tuple) else res
+                red = self.band_sums(full, bands[0], bands[1])
+                if out is not None:
+                    out.copy_(red)
+                    red = out
+                return (red,) + tuple(res[1:]) if isinstance(res, tuple) else red
+            band_out = self.empty(n_items, m, m, nb) if out is None else out
+            assert band_out.is_contiguous() and tuple(band_out.shape) == (n_items, m, m, nb)
         chunk = self.sliding_chunk(n_items, m, p, F) if chunk is None else int(chunk)
-        nbytes = int(self.lib.hmv_sliding_workspace_bytes(chunk, m, p, F))
+        wsf = self.lib.hmv_sliding_workspace_bytes if band_out is None else self.lib.hmv_sliding_bands_workspace_bytes
+        nbytes = int(wsf(chunk, m, p, F))
         ws = self._workspace(nbytes)
         aux = self.aux_stream().cuda_stream if overlap else 0
-        if out is None:
+        if out is None and band_out is None:
             out = self.empty(n_items, m, m, F)
         ar = self.empty(n_items, mp, mp, p) if return_ar else None
         V = self.empty(n_items, mp, mp) if return_ar else None
@@ -395,12 +436,22 @@ class Engine:
                 raise ValueError("grid = (hop, first, n_win) contradicts item_rec / item_start "
                                  "(items must be recording-major, window-minor on the declared grid)")
         with torch.cuda.device(self.device):
-            rc = self.lib.hmv_sliding_ffdtf_f64(
-                x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
-                m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
-                info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
-                g_hop, g_first, g_nwin, T, k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0, self.stream(), aux)
-        _lib.check(rc, "hmv_sliding_ffdtf_f64")
+            if band_out is None:
+                rc = self.lib.hmv_sliding_ffdtf_f64(
+                    x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
+                    m, int(n), int(p), f.data_ptr(), F, float(fs), out.data_ptr(), _ptr(ar), _ptr(V),
+                    info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
+                    g_hop, g_first, g_nwin, T, k3_events[0] if k3_events else 0, k3_events[1] if k3_events else 0,
+                    self.stream(), aux)
+            else:
+                rc = self.lib.hmv_sliding_ffdtf_bands_f64(
+                    x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
+                    m, int(n), int(p), f.data_ptr(), F, float(fs), band_out.data_ptr(), b_lo.data_ptr(), b_hi.data_ptr(), nb,
+                    _ptr(ar), _ptr(V), info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau,
+                    int(flags), g_hop, g_first, g_nwin, T, k3_events[0] if k3_events else 0,
+                    k3_events[1] if k3_events else 0, self.stream(), aux)
+                out = band_out
+        _lib.check(rc, "hmv_sliding_ffdtf_f64" if band_out is None else "hmv_sliding_ffdtf_bands_f64")
         if check == "nan":          # keep the good windows, NaN-fill the ones whose fit or inverse was singular
             badw = (info_yw != 0) | (info_tf.view(n_items, F) != 0).any(dim=1)
             if bool(badw.any()):
@@ -416,7 +467,7 @@ class Engine:
 
 
     # ------------------------------------------------------------------ recordings streamed from the host
-    def stream_dyads(self, dyads, n: int, positions, p: int, freqs, fs: float, bands=None, reduce=None, depth: int = 2,
+    def stream_dyads(self, dyads, n: int, positions, p: int, freqs, fs: float, bands=None, reduce=None, depth: int = 3,
                      check="nan", keep_full=None, timeline=None, out=None):
         """The reference's outer loop -- load a recording, compute, save, next (eeg_alpha_ibi_ffdtf.py:661-806) -- as a
         pipeline: while recording d computes, recording d + 1 crosses PCIe on a copy stream and the reduced result of
@@ -426,6 +477,9 @@ class Engine:
         ffDTF (windows, m, m, n_bands) of `bands` (`distributed.DEFAULT_BANDS`): full-resolution ffDTF is 5 GB per
         10-minute dyad, i.e. >= 80 ms of PCIe against ~10 ms of compute.  `keep_full(d, ffdtf_device)` is called (on the
         compute stream's timeline) for callers that want to consume the full array on the device.
+        `depth`: recordings in flight (buffer slots).  With two, "result of d - 2 on the host -> upload of d -> compute of
+        d" is a chain as long as a dyad's compute and the compute stream waits for its input (0.84 of the resident rate,
+        measured); the third slot takes the copies off the critical path.
         Returns the list of reduced results as NumPy arrays, in order.  `out`: optional pinned host tensor
         (n_recordings, *reduced shape) that receives the results directly (no host-side copy: at 98 MB per 10-minute
         dyad that copy alone takes longer than the dyad's compute); the returned arrays are then views of it.  Same
@@ -436,6 +490,9 @@ class Engine:
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         fhost = f.cpu().numpy()
         lo, hi = hdist.band_bins(fhost, hdist.DEFAULT_BANDS if bands is None else bands)
+        # default product without a consumer of the full array: K3's row workers add the bands up themselves and the 5 GB
+        # per dyad are never written (`sliding_ffdtf(bands=...)`); same bits as band_sums(full array)
+        in_kernel_bands = (reduce is None and keep_full is None)
         if reduce is None:
             def reduce(ff):
                 return self.band_sums(ff, lo, hi)
@@ -446,8 +503,19 @@ class Engine:
         import collections
         import time
         comp = torch.cuda.current_stream(dev)
-        s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        slots, results, pending = [], [], collections.deque()
+        s_in, s_out = self.copy_streams()
+        slots, results, pending, deferred = [], [], collections.deque(), None
+        # timeline: besides the host-side marks, the device-side intervals of every recording (HIP events on the three
+        # streams, read after the last recording): when its upload, its kernels and its download started and ended
+        tev = [] if timeline is not None else None
+        if tev is not None:
+            t_base = torch.cuda.Event(enable_timing=True)
+            t_base.record(comp)
+
+        def mark(stream):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
 
         def collect_one():
             d, k = pending.popleft()
@@ -459,12 +527,16 @@ class Engine:
         for d, arr in enumerate(dyads):
             k = d % depth
             while pending and pending[0][0] <= d - depth:      # slot k's previous recording: result on the host first
+                if deferred is not None and pending[0][0] == d - 1:     # (depth 1: its download is not even queued yet)
+                    deferred()
+                    deferred = None
                 collect_one()
             pinned_in = isinstance(arr, torch.Tensor) and arr.is_pinned()
             host = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
             m, T = host.shape
             if len(slots) <= k:
-                slots.append({"x": self.empty(1, m, T), "ff": self.empty(len(pos), m, m, int(f.numel())), "in_pin": None,
+                slots.append({"x": self.empty(1, m, T),
+                              "ff": None if in_kernel_bands else self.empty(len(pos), m, m, int(f.numel())), "in_pin": None,
                               "h2d": torch.cuda.Event(), "done": torch.cuda.Event(), "d2h": torch.cuda.Event(),
                               "red": None, "out_pin": None})
             sl = slots[k]
@@ -482,47 +554,87 @@ class Engine:
             with torch.cuda.stream(s_in):
                 if d >= depth:
                     s_in.wait_event(sl["done"])                # the kernels that read x[k] have finished
+                if tev is not None:
+                    tev.append({"d": d, "h0": mark(s_in)})
                 sl["x"][0].copy_(src, non_blocking=True)
                 sl["h2d"].record(s_in)
+                if tev is not None:
+                    tev[-1]["h1"] = mark(s_in)
+            # The download of the PREVIOUS recording is queued only now, behind this recording's upload: both directions
+            # go through one in-order copy queue, and a download queued first -- it waits for its kernels -- keeps the
+            # next upload, and with it the next recording's kernels, waiting too (device timeline of the first
+            # recordings, tools/dbg/e2e_depth.py: compute -> download -> upload -> compute, nothing overlapped)
+            if deferred is not None:
+                deferred()
+                deferred = None
             comp.wait_event(sl["h2d"])
-            ff, bad = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["ff"], check="mask", grid=grid,
-                                         validate=not validated)
+            if tev is not None:
+                tev[-1]["c0"] = mark(comp)
+            if in_kernel_bands:
+                if sl["red"] is None:
+                    sl["red"] = self.empty(len(pos), m, m, len(lo))
+                elif d >= depth:
+                    comp.wait_event(sl["d2h"])                 # (already collected on the host: a formality)
+                red, bad = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["red"], check="mask",
+                                              grid=grid, validate=not validated, bands=(lo, hi))
+            else:
+                ff, bad = self.sliding_ffdtf(sl["x"], item_rec, item_start, n, p, f, fs, out=sl["ff"], check="mask", grid=grid,
+                                             validate=not validated)
+                if keep_full is not None:
+                    if check == "nan":
+                        ff.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
+                    keep_full(d, ff)
+                red = reduce(ff)
             validated = True
-            if keep_full is not None:
-                if check == "nan":
-                    ff.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
-                keep_full(d, ff)
-            red = reduce(ff)
             if check == "nan" and red.shape[0] == bad.shape[0]:     # NaN-fill what leaves the device (98 MB, not 5 GB)
                 red.masked_fill_(bad.view(-1, *([1] * (red.dim() - 1))), float("nan"))
-            if sl["red"] is None or sl["red"].shape != red.shape:
-                sl["red"] = torch.empty_like(red)
+            if d < depth:                                      # first use of this slot: where the result goes on the host
                 if out is None:
                     sl["out_pin"] = torch.empty(red.shape, dtype=red.dtype).pin_memory()
                 elif not (out.is_pinned() and tuple(out.shape[1:]) == tuple(red.shape) and out.dtype == red.dtype):
                     raise ValueError("stream_dyads: `out` must be a pinned host tensor (recordings, *%s)" % (tuple(red.shape),))
-            elif d >= depth:
-                comp.wait_event(sl["d2h"])                     # (already collected on the host: a formality)
-            sl["red"].copy_(red)
+            if not in_kernel_bands:                            # (in-kernel bands: `red` IS the slot's buffer)
+                if sl["red"] is None or sl["red"].shape != red.shape:
+                    sl["red"] = torch.empty_like(red)
+                elif d >= depth:
+                    comp.wait_event(sl["d2h"])                 # (already collected on the host: a formality)
+                sl["red"].copy_(red)
             sl["done"].record(comp)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(sl["done"])
-                (out[d] if out is not None else sl["out_pin"]).copy_(sl["red"], non_blocking=True)
-                sl["d2h"].record(s_out)
+            if tev is not None:
+                tev[-1]["c1"] = mark(comp)
+            def download(sl=sl, d=d, te=(tev[-1] if tev is not None else None)):
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(sl["done"])
+                    if te is not None:
+                        te["o0"] = mark(s_out)
+                    (out[d] if out is not None else sl["out_pin"]).copy_(sl["red"], non_blocking=True)
+                    sl["d2h"].record(s_out)
+                    if te is not None:
+                        te["o1"] = mark(s_out)
+            deferred = download
             pending.append((d, k))
             if timeline is not None:
                 timeline.append(("queued", d, time.perf_counter()))
+        if deferred is not None:
+            deferred()
         while pending:
             collect_one()
+        if tev is not None:
+            torch.cuda.synchronize(dev)
+            for t in tev:
+                timeline.append(("device_ms", t["d"], {k: t_base.elapsed_time(t[k]) for k in ("h0", "h1", "c0", "c1", "o0", "o1")}))
         return results
 
     # ------------------------------------------------------------------ ffDTF + spectra from ONE fit
     def sliding_ffdtf_spectra(self, x: torch.Tensor, item_rec: torch.Tensor, item_start: torch.Tensor, n: int, p: int,
-                              freqs, fs: float, chunk: int = 64, check: bool = True, out_ff=None, out_S=None):
+                              freqs, fs: float, chunk: int | None = None, check: bool = True, out_ff=None, out_S=None,
+                              grid=None, flags: int = 0):
         """Both products the reference's orchestrators always compute together (full_freq_dtf + multivariate_spectra,
         /root/reference/src/eeg_alpha_ibi_ffdtf.py:592-604, src/mtmvar.py:1100-1113) from ONE fit and ONE set of
-        inverses per window: K1 -> K2 -> K3 (ffDTF normalised in-kernel, H out) -> K5 -> layout transpose, `chunk` windows at a time
-        (H and S are 16.8 MB per window each).  Returns (ffdtf (items, m, m, F) real, S (items, m, m, F) complex)."""
+        inverses per window, in ONE C-ABI call (`hmv_sliding_ffdtf_spectra_f64`): K1 -> K2 -> K3 (ffDTF normalised
+        in-kernel, H left in the workspace) -> K5 (S written in the reference's (m, m, F) layout), `chunk` windows at a
+        time (H is 16.8 MB per window; default: as many as `max_workspace_bytes` allows).  grid / flags as in
+        `sliding_ffdtf`.  Returns (ffdtf (items, m, m, F) real, S (items, m, m, F) complex)."""
         assert x.dim() == 3 and x.dtype == torch.float64 and x.is_cuda
         x = x if x.stride(2) == 1 else x.contiguous()
         n_rec, m, T = x.shape
@@ -530,37 +642,36 @@ class Engine:
         n_items = int(item_rec.numel())
         f = freqs if isinstance(freqs, torch.Tensor) else self.to_device(np.asarray(freqs, dtype=np.float64))
         F = int(f.numel())
-        tw = self.empty(F, p, 2)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.hmv_twiddles_f64(f.data_ptr(), F, float(fs), p, tw.data_ptr(), self.stream()),
-                       "hmv_twiddles_f64")
         ff = self.empty(n_items, m, m, F) if out_ff is None else out_ff
         S = self.empty(n_items, m, m, F, 2) if out_S is None else out_S
-        infos = []
-        for i0 in range(0, n_items, chunk):
-            sl = slice(i0, min(n_items, i0 + chunk))
-            R = self.lagcov(x, item_rec[sl], item_start[sl], n, p)
-            ar, V, _, info_yw = self.yw_solve(R, m)
-            c, mp = ar.shape[0], ar.shape[1]
-            H = self.empty(c, F, mp, mp, 2)
-            den = self.empty(c, mp)
-            info_tf = self.empty(c * F, dtype=torch.int32)
-            nws = int(self.lib.hmv_tf_ffdtf_workspace_bytes(c, m, p, F))
-            ws = self._workspace(nws)
-            with torch.cuda.device(self.device):
-                # K3 with the ffDTF normalisation inside AND H out: one set of inverses for both products
-                _lib.check(self.lib.hmv_tf_ffdtf_f64(ar.data_ptr(), c, m, p, tw.data_ptr(), F, ff[sl].data_ptr(),
-                                                     den.data_ptr(), H.data_ptr(), info_tf.data_ptr(), self.pivot_tau,
-                                                     ws.data_ptr(), nws, 0, 0, 0, self.stream()), "hmv_tf_ffdtf_f64")
-                # K5 writes S in the reference's (m, m, F) layout itself (no transposition pass over 16.8 MB per window)
-                _lib.check(self.lib.hmv_spectra_mmf_f64(H.data_ptr(), V.data_ptr(), S[sl].data_ptr(), c, m, F, self.stream()),
-                           "hmv_spectra_mmf_f64")
-            t = {"info": info_tf}
-            infos.append((info_yw, t["info"]))
+        if n_items == 0:
+            return ff, torch.view_as_complex(S)
+        if chunk is None:
+            per_item = int(self.lib.hmv_sliding_spectra_workspace_bytes(1, m, p, F))
+            chunk = max(1, min(n_items, self.max_workspace_bytes // max(per_item, 1)))
+        chunk = int(chunk)
+        nbytes = int(self.lib.hmv_sliding_spectra_workspace_bytes(chunk, m, p, F))
+        ws = self._workspace(nbytes)
+        info_yw = self.empty(n_items, dtype=torch.int32)
+        info_tf = self.empty(n_items * F, dtype=torch.int32)
+        g_hop, g_first, g_nwin = (int(v) for v in grid) if grid is not None else (0, 0, 0)
+        if grid is not None:
+            if g_nwin < 1 or n_items % g_nwin or g_hop < 1 or n_items // g_nwin > n_rec:
+                raise ValueError("grid = (hop, first, n_win) does not match the number of items / recordings")
+            k = torch.arange(n_items, dtype=torch.int64, device=self.device)
+            if not (torch.equal(item_rec, k // g_nwin) and torch.equal(item_start, g_first + (k % g_nwin) * g_hop)):
+                raise ValueError("grid = (hop, first, n_win) contradicts item_rec / item_start "
+                                 "(items must be recording-major, window-minor on the declared grid)")
+        with torch.cuda.device(self.device):
+            rc = self.lib.hmv_sliding_ffdtf_spectra_f64(
+                x.data_ptr(), x.stride(0), x.stride(1), item_rec.data_ptr(), item_start.data_ptr(), n_items,
+                m, int(n), int(p), f.data_ptr(), F, float(fs), ff.data_ptr(), S.data_ptr(), 0, 0,
+                info_yw.data_ptr(), info_tf.data_ptr(), ws.data_ptr(), nbytes, chunk, self.pivot_tau, int(flags),
+                g_hop, g_first, g_nwin, T, self.stream(), self.aux_stream().cuda_stream)
+        _lib.check(rc, "hmv_sliding_ffdtf_spectra_f64")
         if check:
-            for info_yw, info_tf in infos:
-                self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
-                self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
+            self.raise_on_info(info_yw, "ar_coeff (Yule-Walker solve)")
+            self.raise_on_info(info_tf, "mvar_transfer_function (inverse of A(f))", per_item=F)
         return ff, torch.view_as_complex(S)
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HMV_VERSION 110            /* 0.1.1 */
+#define HMV_VERSION 120            /* 0.1.2 */
 #define HMV_MAX_CHANNELS 64
 #define HMV_MAX_ORDER 32
 
@@ -198,6 +198,20 @@ int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const doub
                      void* workspace, int64_t workspace_bytes, int64_t flags,
                      void* ev_k3_start, void* ev_k3_stop, void* stream);
 
+/* The same pass with a REDUCED product: band_out[item][i][j][b] = sum_{bin_lo[b] <= f < bin_hi[b]} ffdtf[item][i][j][f]
+ * (bin_lo / bin_hi: int32 device arrays of n_bands entries) -- what the reference's graph plots integrate
+ * (src/mtmvar.py:984-987) and what crosses PCIe / xGMI per window instead of the 8.4 MB of the full array.  The row
+ * workers inside K3 add the bands up from the published |H|^2 rows and the full-resolution array is never written
+ * (only the last few windows of a batch pass through a scratch copy of it).  Same bits as hmv_tf_ffdtf_f64 followed by
+ * hmv_band_sums_f64.  Needs F % 32 == 0 and F <= ~2700 / 1300 / 640 at 64 / 32 / 16 padded channels (one band's weights
+ * must fit the row worker's LDS block); otherwise -10 and the caller takes the two-call route. */
+int64_t hmv_tf_ffdtf_bands_workspace_bytes(int64_t n_items, int m, int p, int F);
+int hmv_tf_ffdtf_bands_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F,
+                           double* band_out, const int32_t* bin_lo, const int32_t* bin_hi, int n_bands,
+                           double* den, int32_t* info, double pivot_tau,
+                           void* workspace, int64_t workspace_bytes, int64_t flags,
+                           void* ev_k3_start, void* ev_k3_stop, void* stream);
+
 /* Fused sliding-window path K1 -> K2 -> K3 -> K4 over all items, processed `chunk` items at a time so the
  * scratch stays bounded.  Equivalent to calling full_freq_dtf(window, freqs, fs, optimal_model_order=p)
  * (src/mtmvar.py:237-284) on every window.  ffdtf: [n_items][m][m][F].
@@ -224,6 +238,38 @@ int hmv_sliding_ffdtf_f64(const double* x, int64_t rec_stride, int64_t ld,
                           double pivot_tau, int64_t flags,
                           int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T,
                           void* ev_k3_start, void* ev_k3_stop, void* stream, void* aux_stream);
+
+/* hmv_sliding_ffdtf_f64 with the reduced product of hmv_tf_ffdtf_bands_f64: band_out: [n_items][m][m][n_bands].  The
+ * per-dyad loop of the reference (load, compute, save: src/eeg_alpha_ibi_ffdtf.py:661-806) streams recordings through
+ * this entry: 154 MB in, 98 MB out per 10-minute dyad instead of 5 GB. */
+int64_t hmv_sliding_bands_workspace_bytes(int64_t chunk, int m, int p, int F);
+int hmv_sliding_ffdtf_bands_f64(const double* x, int64_t rec_stride, int64_t ld,
+                                const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
+                                int m, int n, int p, const double* freqs, int F, double fs,
+                                double* band_out, const int32_t* bin_lo, const int32_t* bin_hi, int n_bands,
+                                double* ar_out, double* V_out,
+                                int32_t* info_yw, int32_t* info_tf,
+                                void* workspace, int64_t workspace_bytes, int64_t chunk,
+                                double pivot_tau, int64_t flags,
+                                int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T,
+                                void* ev_k3_start, void* ev_k3_stop, void* stream, void* aux_stream);
+
+/* hmv_sliding_ffdtf_f64 that ALSO returns the multivariate spectra S(f) = H(f) V H(f)^T (plain transpose, as
+ * src/mtmvar.py:199) of every window -- the two products the reference's orchestrators always compute together, there
+ * from two separate fits (src/eeg_alpha_ibi_ffdtf.py:592-604, src/mtmvar.py:1100-1113), here from ONE fit and ONE set of
+ * inverses: K3 leaves H of a chunk in the workspace, K5 turns it into S_out: complex128 [n_items][m][m][F] (the
+ * reference's layout).  V is this library's own residual covariance, symmetric up to rounding, so K5 computes the upper
+ * triangle of S only and mirrors it (S_ij and S_ji of the reference differ by rounding; here they are equal). */
+int64_t hmv_sliding_spectra_workspace_bytes(int64_t chunk, int m, int p, int F);
+int hmv_sliding_ffdtf_spectra_f64(const double* x, int64_t rec_stride, int64_t ld,
+                                  const int64_t* item_rec, const int64_t* item_start, int64_t n_items,
+                                  int m, int n, int p, const double* freqs, int F, double fs,
+                                  double* ffdtf, double* S_out, double* ar_out, double* V_out,
+                                  int32_t* info_yw, int32_t* info_tf,
+                                  void* workspace, int64_t workspace_bytes, int64_t chunk,
+                                  double pivot_tau, int64_t flags,
+                                  int64_t grid_hop, int64_t grid_first, int64_t grid_nwin, int64_t grid_T,
+                                  void* stream, void* aux_stream);
 
 #ifdef __cplusplus
 }

@@ -65,10 +65,23 @@ bad = [
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 65, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 64, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
     lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 3, 4, 100, 4, 0, 8, 100.0, D, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    # the reduced-product entries: band bins missing, grids the row workers cannot take, unfused flag, null output
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 32, D, 0, D, 2, D, D, 1.0, D, 1 << 30, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 48, D, D, D, 2, D, D, 1.0, D, 1 << 30, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 672, D, D, D, 2, D, D, 1.0, D, 1 << 30, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 32, D, D, D, 2, D, D, 1.0, D, 1 << 30, 1, 0, 0, 0),
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 32, 0, D, D, 2, D, D, 1.0, D, 1 << 30, 0, 0, 0, 0),
+    lib.hmv_tf_ffdtf_bands_f64(D, 5, 4, 2, D, 32, D, D, D, 2, D, D, 1.0, D, 16, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_bands_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 32, 100.0, D, D, 0, 2, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_bands_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 32, 100.0, 0, D, D, 2, 0, 0, D, D, D, 1 << 30, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
+    lib.hmv_sliding_ffdtf_bands_f64(D, 0, 0, D, D, 3, 4, 100, 4, D, 32, 100.0, D, D, D, 2, 0, 0, D, D, D, 64, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0),
 ]
 assert all(rc < 0 for rc in bad), bad
 assert lib.hmv_sliding_ffdtf_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 8, 100.0, D, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == 0
 assert lib.hmv_tf_ffdtf_f64(D, 0, 4, 2, D, 4, D, D, 0, D, 1.0, D, 0, 0, 0, 0, 0) == 0        # empty batches: nothing to do
+assert lib.hmv_sliding_ffdtf_bands_f64(D, 0, 0, D, D, 0, 4, 100, 4, D, 32, 100.0, D, D, D, 2, 0, 0, D, D, D, 0, 3, 1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == 0
+assert lib.hmv_tf_ffdtf_bands_workspace_bytes(30, 64, 8, 256) > lib.hmv_tf_ffdtf_workspace_bytes(30, 64, 8, 256) > 0
+assert lib.hmv_sliding_bands_workspace_bytes(30, 64, 8, 256) > lib.hmv_sliding_workspace_bytes(30, 64, 8, 256) > 0
 assert len(lib.hmv_last_error()) > 0
 # tuning knobs: range-checked, readable back, process-wide
 assert lib.hmv_set_tuning(1, 16) == 0 and lib.hmv_get_tuning(1) == 16 and lib.hmv_set_tuning(1, 0) == 0

@@ -455,6 +455,78 @@ def test_normalisation_inside_k3_with_a_short_lag(m, n, p, F, nw, lag):
     assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
 
 
+@pytest.mark.parametrize("m,n,p,F,nw,lag,bins", [
+    (64, 1000, 8, 256, 40, 9, [(0, 8), (8, 16), (16, 26), (26, 60), (60, 90)]),
+    (64, 1000, 8, 32, 60, 8, [(0, 32), (3, 4), (5, 5), (30, 32), (0, 1), (7, 21), (16, 17)]),       # 7 bands: two passes
+    (33, 300, 2, 64, 200, 8, [(0, 64), (10, 11)]),
+    (19, 400, 3, 32, 150, 8, [(1, 31), (0, 2), (31, 32)]),
+    (4, 160, 5, 640, 300, 8, [(0, 640), (100, 101), (320, 640)]),     # 16 padded channels: ONE band's weights per pass
+    (48, 600, 4, 96, 200, 8, [(0, 96), (95, 96), (40, 41), (0, 0), (1, 2), (3, 96)])])
+def test_band_sums_inside_k3_equal_band_sums_of_the_full_array(m, n, p, F, nw, lag, bins):
+    """The reduced product (`sliding_ffdtf(bands=...)`, hmv_sliding_ffdtf_bands_f64): K3's row workers add the frequency
+    bands up from the published |H|^2 rows and the (items, m, m, F) array is never written -- the same BITS as
+    `band_sums(sliding_ffdtf(...))`, for every window: the ones whose rows are reduced inside K3, the rows that come up
+    early (missed-row list) and the last `lag` windows (K4 into scratch + the band-sum kernel).  Overlapping, empty,
+    one-bin and full-grid bands; more bands than one pass holds; every padded size; the workspace reused twice; chunks."""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    assert eng.bands_in_kernel(m, F)
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(17, m=m, p=min(p, 4), T=T, burn=300)
+    freqs = np.linspace(0.5, 120.0, F)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    lo, hi = [b[0] for b in bins], [b[1] for b in bins]
+    full = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0)
+    want = eng.band_sums(full, lo, hi)
+    ref = full.cpu().numpy()
+    for b, (l0, h0) in enumerate(bins):        # the band-sum kernel itself against NumPy
+        assert np.allclose(want[..., b].cpu().numpy(), ref[..., l0:h0].sum(axis=-1), rtol=1e-12, atol=1e-300)
+    assert eng.lib.hmv_set_tuning(_lib.TUNE_NORM_LAG, lag) == 0
+    try:
+        got = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, bands=(lo, hi))
+        again = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, bands=(lo, hi))
+        chunked = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, bands=(lo, hi), chunk=max(lag + 3, nw // 3 + 1))
+        torch.cuda.synchronize()
+    finally:
+        assert eng.lib.hmv_set_tuning(_lib.TUNE_NORM_LAG, 0) == 0
+    default_lag = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, bands=(lo, hi))
+    assert got.shape == (nw, m, m, len(bins))
+    assert torch.equal(got, want) and torch.equal(again, want) and torch.equal(chunked, want) and torch.equal(default_lag, want)
+
+
+def test_band_sums_fall_back_to_two_calls_on_other_grids():
+    """A grid that is not a multiple of 32 frequencies (or too long for the row worker's LDS block) cannot be reduced
+    inside K3: `sliding_ffdtf(bands=...)` then computes the full array and sums it -- same result, and the C entry point
+    itself refuses (-10) instead of computing something else."""
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    m, n, p, F, nw = 19, 400, 3, 48, 12
+    assert not eng.bands_in_kernel(m, F) and not eng.bands_in_kernel(4, 672) and eng.bands_in_kernel(4, 640)
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(18, m=m, p=3, T=T, burn=300)
+    freqs = np.linspace(0.5, 120.0, F)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    lo, hi = [0, 10], [48, 20]
+    got = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, bands=(lo, hi))
+    want = eng.band_sums(eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0), lo, hi)
+    assert torch.equal(got, want)
+    ar = eng.empty(2, 32, 32, p)
+    tw = eng.twiddles(freqs, 500.0, p)
+    b_lo, b_hi = eng.band_tables(lo, hi, F)
+    nws = int(eng.lib.hmv_tf_ffdtf_bands_workspace_bytes(2, m, p, F))
+    ws = eng.empty(nws // 8 + 1)
+    rc = eng.lib.hmv_tf_ffdtf_bands_f64(ar.data_ptr(), 2, m, p, tw.data_ptr(), F, eng.empty(2, m, m, 2).data_ptr(),
+                                        b_lo.data_ptr(), b_hi.data_ptr(), 2, eng.empty(2, 32).data_ptr(),
+                                        eng.empty(2 * F, dtype=torch.int32).data_ptr(), 0.25, ws.data_ptr(), nws, 0, 0, 0,
+                                        eng.stream())
+    assert rc == -10 and b"F % 32" in eng.lib.hmv_last_error()
+
+
 @pytest.mark.parametrize("m,p,F,scale", [(64, 8, 32, 0.05), (64, 2, 16, 3.0), (50, 5, 16, 2.0), (64, 16, 16, 0.3),
                                           (64, 1, 16, 5.0), (57, 3, 48, 1.0), (64, 7, 16, 0.5)])
 def test_hand_scheduled_k3_body_equals_compiler_body(m, p, F, scale):
@@ -636,12 +708,16 @@ def test_lag_covariances_from_shared_hop_blocks(m, n, hop, p, T, first):
         eng.lagcov_regular(xd[0], first, hop, n_win + 1 + (T - first - n) // hop, n, p)       # past the recording
 
 
-@pytest.mark.parametrize("m,n,p,F,nw,chunk", [(64, 1000, 8, 32, 40, 33), (19, 400, 3, 20, 9, 4), (4, 160, 5, 30, 5, 64)])
+@pytest.mark.parametrize("m,n,p,F,nw,chunk", [(64, 1000, 8, 32, 40, 33), (19, 400, 3, 20, 9, 4), (4, 160, 5, 30, 5, 64),
+                                               (64, 1000, 8, 64, 12, None), (48, 600, 4, 64, 20, 7), (33, 300, 2, 128, 12, None)])
 def test_ffdtf_and_spectra_of_every_window_from_one_fit(m, n, p, F, nw, chunk):
-    """`Engine.sliding_ffdtf_spectra`: what the reference's orchestrators compute per window with two separate fits
-    (full_freq_dtf + multivariate_spectra, eeg_alpha_ibi_ffdtf.py:592-604) from ONE fit and ONE set of inverses, batched.
-    ffDTF equals the ffDTF-only path bit for bit (same K1 form), spectra equal the oracle's H V H^T (plain transpose)."""
-    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    """`Engine.sliding_ffdtf_spectra` (hmv_sliding_ffdtf_spectra_f64): what the reference's orchestrators compute per
+    window with two separate fits (full_freq_dtf + multivariate_spectra, eeg_alpha_ibi_ffdtf.py:592-604) from ONE fit and
+    ONE set of inverses, batched.  ffDTF equals the ffDTF-only path bit for bit (same K1 form, with and without a declared
+    grid), spectra equal the oracle's H V H^T (plain transpose); K5 computes the upper triangle only (V is the fit's own
+    symmetric estimate) and mirrors it, so S is EXACTLY symmetric where the reference's is symmetric to rounding; every
+    padded size, grids that are and are not a multiple of 64 frequencies (the (m, m, F) store map differs)."""
+    from hyperscanning_signal_analysis_amd.sliding import regular_grid, window_items, window_positions
     eng = default_engine()
     T = n * (nw + 1) // 2
     x = synthetic_var_dyad(17, m=m, p=min(p, 4), T=T, burn=300)
@@ -654,10 +730,16 @@ def test_ffdtf_and_spectra_of_every_window_from_one_fit(m, n, p, F, nw, chunk):
     torch.cuda.synchronize()
     assert ff.shape == (nw, m, m, F) and S.shape == (nw, m, m, F) and S.dtype == torch.complex128
     assert torch.equal(ff, only)
+    assert torch.equal(S, S.transpose(1, 2))
     for k in (0, nw // 2, nw - 1):
         wk = x[:, pos[k]:pos[k] + w]
         assert_parity(S[k].cpu().numpy(), O.multivariate_spectra(wk, freqs, 500.0, p), 1e-8)
         assert_parity(ff[k].cpu().numpy(), O.full_freq_dtf(wk, freqs, 500.0, p), 1e-8)
+    grid = regular_grid(pos, w, p)
+    if grid is not None:                        # K1 from shared hop blocks: the same path as sliding_ffdtf(grid=...)
+        ffg, Sg = eng.sliding_ffdtf_spectra(xd, rec, st, w, p, freqs, 500.0, chunk=chunk, grid=grid)
+        assert torch.equal(ffg, eng.sliding_ffdtf(xd, rec, st, w, p, freqs, 500.0, grid=grid))
+        assert float((Sg - S).abs().max() / S.abs().max()) < 1e-10 and torch.equal(Sg, Sg.transpose(1, 2))
 
 
 def test_in_kernel_normalisation_with_changing_data_in_the_same_workspace():
