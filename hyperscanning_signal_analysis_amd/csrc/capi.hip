@@ -21,7 +21,7 @@ inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
 // Tuning knobs: the environment is parsed once, at load time, with range checks; hmv_set_tuning overrides.
 constexpr int N_TUNE = 6;
 struct TuneRange { long long lo, hi; };
-constexpr TuneRange kTuneRange[N_TUNE] = {{0, 0}, {0, 1 << 20}, {0, 3}, {0, 2}, {0, 2}, {0, 140000}};
+constexpr TuneRange kTuneRange[N_TUNE] = {{0, 0}, {0, 1 << 20}, {0, 3}, {0, 2}, {0, 3}, {0, 140000}};
 long long env_knob(const char* name, int key) {
   const char* e = getenv(name);
   if (!e || !*e) return 0;

@@ -54,6 +54,7 @@ struct YwArgs {
 long long yw_ws_tiles(int p);
 int launch_yw(const YwArgs& a, int m_pad, hipStream_t st);
 int launch_yw_lwr(const YwArgs& a, int m_pad, hipStream_t st);
+int launch_yw_lwr2(const YwArgs& a, int m_pad, hipStream_t st);
 
 // ---- K3 transfer matrix inverse ---------------------------------------------------------------
 struct TfArgs {

@@ -16,10 +16,10 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
   } while (0)
 
 __host__ __device__ inline long long yw_tri(int a, int b) { return (long long)a * (a + 1) / 2 + b; }
-// scratch tiles per window: the LDL^T form needs 2 T(p+1) + 2p, the Levinson-Whittle form 4p + 5; one more tile at the
+// scratch tiles per window: the LDL^T form needs 2 T(p+1) + 2p, the Levinson-Whittle form 4p + 6; one more tile at the
 // end belongs to neither (its last int is the window's "re-solve with the LDL^T" flag: yw_guard_ptr)
 __host__ __device__ inline long long yw_ws_tiles_d(int p) {
-  const long long a = 2 * yw_tri(p + 1, 0) + 2 * (long long)p, b = 4 * (long long)p + 5;
+  const long long a = 2 * yw_tri(p + 1, 0) + 2 * (long long)p, b = 4 * (long long)p + 6;
   return (a > b ? a : b) + 1;
 }
 __host__ __device__ inline int* yw_guard_ptr(double* ws, long long item, int p, int tile) {

@@ -287,8 +287,11 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
   }
 }
 
+// HMV_TUNE_YW_FORM = 3 takes the software-pipelined form of the same recursion (yw_lwr2.hip): measured equal in time
+// (1.73 vs 1.74 ms at 599 windows) and 4 % lower in HBM traffic -- see profiles/r03_k2_notes.md -- so this one stays
 int launch_yw_lwr(const YwArgs& a, int m_pad, hipStream_t st) {
   if (a.n_items == 0) return 0;
+  if (tuning(4 /* HMV_TUNE_YW_FORM */) == 3) return launch_yw_lwr2(a, m_pad, st);
   const dim3 grid((unsigned)a.n_items), block(256);
   const bool vq = (a.Vq_logdet != nullptr);
   switch (m_pad) {

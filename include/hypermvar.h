@@ -42,7 +42,8 @@ int hmv_pad(int m);
  *   HMV_TUNE_NORM_LAG   windows between a K3 workgroup and the window whose rows it normalises (0 = built-in rule, >= 8)
  *   HMV_TUNE_LAG_GROUP  lags per K1 workgroup (1..3; 0 = default 3)
  *   HMV_TUNE_K3_FORM    0 = default, 1 = compiler-scheduled K3 body, 2 = hand-scheduled 64-channel K3 body
- *   HMV_TUNE_YW_FORM    0 = default, 1 = block LDL^T of the augmented matrix, 2 = block Levinson-Whittle recursion
+ *   HMV_TUNE_YW_FORM    0 = default, 1 = block LDL^T of the augmented matrix, 2 = block Levinson-Whittle recursion,
+ *                       3 = the same recursion as a software pipeline (yw_lwr2.hip; equal in time, measurement form)
  *   HMV_TUNE_K3_LDS_PAD bytes of unused dynamic LDS added to every K3 workgroup (measurement only: fewer resident
  *                       workgroups per CU, to separate latency from throughput; 0 = none)
  * Returns 0, or -1 for an unknown key / value out of range.  hmv_get_tuning returns the value in force (-1: unknown key). */

@@ -39,9 +39,9 @@ def test_header_symbols_all_exported(lib):
 def test_argument_checks_without_gpu(lib):
     assert lib.hmv_pad(3) == 16 and lib.hmv_pad(16) == 16 and lib.hmv_pad(19) == 32 and lib.hmv_pad(64) == 64
     assert lib.hmv_pad(0) == -1 and lib.hmv_pad(65) == -1
-    # K2 scratch: the larger of the two solvers' needs (block LDL^T: 2 T(p+1) + 2p tiles; recursion: 4p + 5) + the guard tile
+    # K2 scratch: the larger of the two solvers' needs (block LDL^T: 2 T(p+1) + 2p tiles; recursion: 4p + 6) + the guard tile
     assert lib.hmv_yw_workspace_doubles(64, 8) == (2 * 45 + 16 + 1) * 64 * 64
-    assert lib.hmv_yw_workspace_doubles(4, 1) == (4 * 1 + 5 + 1) * 16 * 16
+    assert lib.hmv_yw_workspace_doubles(4, 1) == (4 * 1 + 6 + 1) * 16 * 16
     assert lib.hmv_sliding_workspace_bytes(1, 64, 8, 256) > 8 * 64 * 64 * 256
     # bad arguments are refused before any launch
     assert lib.hmv_lagcov_f64(0, 0, 0, 0, 0, 1, 65, 100, 4, 0, 0) == -1

@@ -455,6 +455,38 @@ def test_normalisation_inside_k3_with_a_short_lag(m, n, p, F, nw, lag):
     assert float((fused.sum(dim=(2, 3)) - 1).abs().max()) < 1e-12
 
 
+@pytest.mark.parametrize("m,n,p,nw", [(64, 1000, 8, 6), (33, 300, 2, 5), (19, 400, 5, 4), (4, 160, 7, 9), (64, 700, 1, 3)])
+def test_pipelined_levinson_whittle_form_equals_the_first_form(m, n, p, nw):
+    """HMV_TUNE_YW_FORM = 3 (csrc/yw_lwr2.hip: the block Levinson-Whittle recursion as a software pipeline, register X
+    operands, accumulators that start from the subtrahend) against the default form and the oracle: ar, V and every
+    order's log det agree to rounding; every padded size, orders 1 .. 8."""
+    from hyperscanning_signal_analysis_amd import _lib
+    from hyperscanning_signal_analysis_amd.sliding import window_items, window_positions
+    eng = default_engine()
+    T = n * (nw + 1) // 2
+    x = synthetic_var_dyad(23, m=m, p=min(p, 4), T=T, burn=300)
+    xd = eng.to_device(x[None])
+    pos, w = window_positions(T, nw, n)
+    rec, st = window_items(1, pos, eng.device)
+    R = eng.lagcov(xd, rec, st, w, p)
+    ar0, V0, ld0, info0 = eng.yw_solve(R, m, want_logdet=True)
+    assert eng.lib.hmv_set_tuning(_lib.TUNE_YW_FORM, 3) == 0
+    try:
+        ar3, V3, ld3, info3 = eng.yw_solve(R, m, want_logdet=True)
+        ar3b, V3b, _, _ = eng.yw_solve(R, m)
+        torch.cuda.synchronize()
+    finally:
+        assert eng.lib.hmv_set_tuning(_lib.TUNE_YW_FORM, 0) == 0
+    assert not bool(info0.any()) and not bool(info3.any())
+    assert torch.equal(ar3, ar3b) and torch.equal(V3, V3b)
+    for a, b in ((ar3, ar0), (V3, V0), (ld3, ld0)):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-9
+    for k in (0, nw - 1):
+        aro, Vo = O.ar_coeff(x[:, pos[k]:pos[k] + w], p)
+        assert_parity(ar3[k, :m, :m].cpu().numpy(), aro, 1e-8)
+        assert_parity(V3[k, :m, :m].cpu().numpy(), Vo, 1e-8)
+
+
 @pytest.mark.parametrize("m,n,p,F,nw,lag,bins", [
     (64, 1000, 8, 256, 40, 9, [(0, 8), (8, 16), (16, 26), (26, 60), (60, 90)]),
     (64, 1000, 8, 32, 60, 8, [(0, 32), (3, 4), (5, 5), (30, 32), (0, 1), (7, 21), (16, 17)]),       # 7 bands: two passes

@@ -19,7 +19,7 @@ for blk in re.split(r"remark: Function Name: ", txt)[1:]:
         print(name[:60], "VGPRs", v.group(1), "spill", sp.group(1), "LDS", lds.group(1), "occ", occ.group(1))
 PY
 OBJS=""
-for f in lagcov yw_solve yw_lwr tf_inv ffdtf_norm spectra connect psd dpss capi; do
+for f in lagcov yw_solve yw_lwr yw_lwr2 tf_inv ffdtf_norm spectra connect psd dpss capi; do
   if [ $f = $SRC ]; then OBJS="$OBJS build/var/${f}_$NAME.o"; else OBJS="$OBJS build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libhypermvar_$NAME.so -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
