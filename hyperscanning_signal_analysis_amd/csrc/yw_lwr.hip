@@ -122,10 +122,38 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
         if (col >= 0 && col < KH) Xh[(4 * (wv * NT + ii) + i) * SH + col] = v[ii][J];
       }
   };
+  // One k-half of a product: KH / 4 k-steps of NIW + NJ operand reads and NIW * NJ MFMAs.  The operands of step s + 1 are
+  // requested BEFORE the MFMAs of step s are issued (two register sets, ping-pong): written as "reads, wait, MFMAs" per
+  // step the LDS latency of every step was exposed -- ~200 of ~450 cycles per step with one wave per SIMD, the reason a
+  // 64^3 product took 10 -- 13 k cycles for 4.1 k cycles of matrix pipe (profiles/r03_k2_notes.md).
+#ifndef HMV_LWR_GEMM_PIPE
+#define HMV_LWR_GEMM_PIPE 1
+#endif
   auto gemm_half = [&](double (&acc)[NIW][NJ]) __attribute__((always_inline)) {
     const int l = lane();
     const double* xa = Xh + (4 * wv * NT + (l & 3)) * SH + (l >> 4);
     const double* yb = Yh + (l & 15) * SH + (l >> 4);
+#if HMV_LWR_GEMM_PIPE
+    constexpr int NS = KH / 4;
+    double av[2][NIW], bv[2][NJ];
+    auto rd = [&](int set, int k0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii) av[set][ii] = xa[4 * ii * SH + k0];
+#pragma unroll
+      for (int J = 0; J < NJ; ++J) bv[set][J] = yb[16 * J * SH + k0];
+    };
+    rd(0, 0);
+    static_for<NS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value, cur = s & 1;
+      if constexpr (s + 1 < NS) rd(cur ^ 1, 4 * (s + 1));
+      __builtin_amdgcn_sched_barrier(0);          // the requests above stay above the MFMAs below
+#pragma unroll
+      for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[cur][ii], bv[cur][J], acc[ii][J]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#else
 #pragma unroll 2
     for (int k0 = 0; k0 < KH; k0 += 4) {
       double av[NIW], bv[NJ];
@@ -138,6 +166,7 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
 #pragma unroll
         for (int J = 0; J < NJ; ++J) acc[ii][J] = mfma4(av[ii], bv[J], acc[ii][J]);
     }
+#endif
   };
   // acc += X' * Y'^T;  X' = srcX (global tile; transposed if trX) or, if srcX == nullptr, the register tile xr;
   // Y' = srcY (transposed if trY).  I.e. trY = false: X' Y^T, trY = true: X' Y.

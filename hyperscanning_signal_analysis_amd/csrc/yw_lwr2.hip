@@ -84,100 +84,133 @@ __global__ void __launch_bounds__(256, 3) yw_lwr2_kernel(YwArgs a) {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
     return lo;
   };
+  // Thread-constant offsets of the staging helpers, computed ONCE (each phase used to re-derive them from the lane id:
+  // ~150 integer instructions per phase, which with one wave per SIMD is as long as the phase's 64 MFMAs -- the stamped
+  // build showed 1.4 k cycles of k-step loop and 1.4 k cycles of everything else per phase).
+  const int tid0 = lane() + 64 * wv;
+  int fo_plain[NVQ], fo_tr[NVQ], po_plain[NVQ], po_tr[NVQ];
+#pragma unroll
+  for (int r = 0; r < NVQ; ++r) {
+    const int idx = tid0 + 256 * r;
+    const int row = idx / (KQ / 2), c2 = idx - row * (KQ / 2);
+    const int k = idx / (MP / 2), d2 = idx - k * (MP / 2);
+    fo_plain[r] = row * MP + 2 * c2;            // + t * KQ
+    fo_tr[r] = k * MP + 2 * d2;                 // + t * KQ * MP
+    po_plain[r] = row * SQ + 2 * c2;
+    po_tr[r] = (2 * d2) * SQ + k;
+  }
+  const int ln = lane();
+  const int xrow0 = (4 * wv * NT + (ln >> 4)) * SQ + (ln & 15);      // parkx: + 4 * ii * SQ + 16 * J - t * KQ
+  const int xa0 = (4 * wv * NT + (ln & 3)) * SQ + (ln >> 4);         // gemmq A operand
+  const int yb0 = (ln & 15) * SQ + (ln >> 4);                        // gemmq B operand
   // ---- Y operand, quarter t of the k range.  Plain image: Y'[row][k] = src[row][t*KQ + k];  transposed image:
   // Y'[col][k] = src[t*KQ + k][col].  (product() computes acc +- X' Y'^T.)
   auto fetchq = [&](f64x2 (&v)[NVQ], const double* src, int t, bool tr) __attribute__((always_inline)) {
-    const int t0 = lane() + 64 * wv;
+    const double* s0 = src + (tr ? t * KQ * MP : t * KQ);
 #pragma unroll
     for (int r = 0; r < NVQ; ++r) {
-      const int idx = t0 + 256 * r;
-      if (FULLQ || idx < MP * KQ / 2) {
-        const int row = idx / (KQ / 2), c2 = idx - row * (KQ / 2);
-        const int k = idx / (MP / 2), d2 = idx - k * (MP / 2);
-        const size_t off = tr ? (size_t)(t * KQ + k) * MP + 2 * d2 : (size_t)row * MP + t * KQ + 2 * c2;
-        v[r] = *reinterpret_cast<const f64x2*>(src + off);
-      }
+      if (FULLQ || tid0 + 256 * r < MP * KQ / 2) v[r] = *reinterpret_cast<const f64x2*>(s0 + (tr ? fo_tr[r] : fo_plain[r]));
     }
   };
   auto parkq = [&](double* dst, const f64x2 (&v)[NVQ], bool tr) __attribute__((always_inline)) {
-    const int t0 = lane() + 64 * wv;
 #pragma unroll
     for (int r = 0; r < NVQ; ++r) {
-      const int idx = t0 + 256 * r;
-      if (FULLQ || idx < MP * KQ / 2) {
+      if (FULLQ || tid0 + 256 * r < MP * KQ / 2) {
         if (!tr) {
-          const int row = idx / (KQ / 2), c2 = idx - row * (KQ / 2);
-          double* d = dst + row * SQ + 2 * c2;
+          double* d = dst + po_plain[r];
           d[0] = v[r].x;
           d[1] = v[r].y;
         } else {
-          const int k = idx / (MP / 2), d2 = idx - k * (MP / 2);
-          dst[(2 * d2) * SQ + k] = v[r].x;
-          dst[(2 * d2 + 1) * SQ + k] = v[r].y;
+          dst[po_tr[r]] = v[r].x;
+          dst[po_tr[r] + SQ] = v[r].y;
         }
       }
     }
   };
   // ---- X operand: this wave's row strip of a register tile, columns t*KQ .. (read back by this wave only)
   auto parkx = [&](const double (&x)[NIW][NJ], int t) __attribute__((always_inline)) {
-    const int l = lane(), i = l >> 4, cc = l & 15;
+    const int cc = ln & 15;
 #pragma unroll
     for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
       for (int J = 0; J < NJ; ++J) {
         const int col = 16 * J + cc - t * KQ;
-        if (col >= 0 && col < KQ) Xq[(4 * (wv * NT + ii) + i) * SQ + col] = x[ii][J];
+        if (col >= 0 && col < KQ) Xq[xrow0 + 4 * ii * SQ + 16 * J - t * KQ] = x[ii][J];
       }
   };
   auto gemmq = [&](double (&acc)[NIW][NJ], const double* Yq, auto negc) __attribute__((always_inline)) {
     constexpr bool NEG = decltype(negc)::value;
-    const int l = lane();
-    const double* xa = Xq + (4 * wv * NT + (l & 3)) * SQ + (l >> 4);
-    const double* yb = Yq + (l & 15) * SQ + (l >> 4);
+    const double* xa = Xq + xa0;
+    const double* yb = Yq + yb0;
+    constexpr int NS = KQ / 4;
+    double av[2][NIW], bv[2][NJ];
+    auto rd = [&](int set, int k0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k0 = 0; k0 < KQ; k0 += 4) {
-      double av[NIW], bv[NJ];
+      for (int ii = 0; ii < NIW; ++ii) av[set][ii] = xa[4 * ii * SQ + k0];
 #pragma unroll
-      for (int ii = 0; ii < NIW; ++ii) av[ii] = xa[4 * ii * SQ + k0];
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) bv[J] = yb[16 * J * SQ + k0];
+      for (int J = 0; J < NJ; ++J) bv[set][J] = yb[16 * J * SQ + k0];
+    };
+    rd(0, 0);
+    static_for<NS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s2 = decltype(sc)::value, cur = s2 & 1;
+      if constexpr (s2 + 1 < NS) rd(cur ^ 1, 4 * (s2 + 1));          // the next step's operands, requested first
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
-        for (int J = 0; J < NJ; ++J) acc[ii][J] = NEG ? mfma4_nega(av[ii], bv[J], acc[ii][J]) : mfma4(av[ii], bv[J], acc[ii][J]);
-    }
+        for (int J = 0; J < NJ; ++J)
+          acc[ii][J] = NEG ? mfma4_nega(av[cur][ii], bv[cur][J], acc[ii][J]) : mfma4(av[cur][ii], bv[cur][J], acc[ii][J]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
   // ---- the pipeline.  Invariant on entry to product(): quarters 0 and 1 of its Y operand are in flight in vy0 / vy1
   // (prime(), or the previous product's last two phases).  Phase t: park Y quarter t in image t & 1 (last read two
   // phases ago, i.e. before the previous phase's barrier), issue the loads of quarter t + 2 (of the next product from
   // t = 2 on), park the X quarter, ONE barrier, MFMAs.  acc +- X Y'^T.
+#ifdef HMV_LWR2_STAMP
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
   f64x2 vy0[NVQ], vy1[NVQ];
   auto prime = [&](const double* src, bool tr) __attribute__((always_inline)) {
     fetchq(vy0, src, 0, tr);
     fetchq(vy1, src, 1, tr);
   };
+#ifdef HMV_LWR2_STAMP
+  auto gemmq_timed = [&](double (&acc)[NIW][NJ], const double* Yq, auto negc) __attribute__((always_inline)) {
+    unsigned long long ta, tb;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta)::"memory");
+    gemmq(acc, Yq, negc);
+    asm volatile("s_nop 0" ::"v"(acc[NIW - 1][NJ - 1]));     // (the last MFMA has been issued)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
+    tsum[7] += tb - ta;
+  };
+#define LWR2_GEMM gemmq_timed
+#else
+#define LWR2_GEMM gemmq
+#endif
   auto product = [&](double (&acc)[NIW][NJ], const double (&x)[NIW][NJ], const double* ysrc, bool ytr, const double* nsrc,
                      bool ntr, auto negc) __attribute__((always_inline)) {
     parkq(Yq0, vy0, ytr);
     fetchq(vy0, ysrc, 2, ytr);
     parkx(x, 0);
     __syncthreads();
-    gemmq(acc, Yq0, negc);
+    LWR2_GEMM(acc, Yq0, negc);
     parkq(Yq1, vy1, ytr);
     fetchq(vy1, ysrc, 3, ytr);
     parkx(x, 1);
     __syncthreads();
-    gemmq(acc, Yq1, negc);
+    LWR2_GEMM(acc, Yq1, negc);
     parkq(Yq0, vy0, ytr);
     if (nsrc) fetchq(vy0, nsrc, 0, ntr);
     parkx(x, 2);
     __syncthreads();
-    gemmq(acc, Yq0, negc);
+    LWR2_GEMM(acc, Yq0, negc);
     parkq(Yq1, vy1, ytr);
     if (nsrc) fetchq(vy1, nsrc, 1, ntr);
     parkx(x, 3);
     __syncthreads();
-    gemmq(acc, Yq1, negc);
+    LWR2_GEMM(acc, Yq1, negc);
   };
   constexpr std::integral_constant<bool, false> POS{};
   constexpr std::integral_constant<bool, true> NEGA{};
@@ -254,10 +287,6 @@ __global__ void __launch_bounds__(256, 3) yw_lwr2_kernel(YwArgs a) {
     __syncthreads();            // the inverse is in global memory for the whole workgroup
   };
 
-#ifdef HMV_LWR2_STAMP
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
-#endif
   double g[NIW][NJ];
   // ---- order 0: Vf = Vb = C(0) = R_0 (symmetric), D_0 = C(1) = R_1^T
   load_tile(g, R, false);
