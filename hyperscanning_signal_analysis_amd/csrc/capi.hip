@@ -366,8 +366,11 @@ int tf_ffdtf_impl(const char* who, const double* ar, int64_t n_items, int m, int
   a.info = info; a.n_items = n_items; a.F = F; a.p = p; a.m = m; a.tau = pivot_tau;
   // the in-kernel normaliser moves 16 bytes per lane: whole 16-frequency lines of a 16-byte aligned output
   const bool fused = bands || (!(flags & HMV_FLAG_UNFUSED_NORM) && (F % 16 == 0) && (reinterpret_cast<uintptr_t>(ffdtf) % 16 == 0));
+  // Every window is published and normalised by this launch: row i of window w < n - lag by a workgroup of window w + lag
+  // inside K3, the rows of the last `lag` windows (and any row that came up before its window was complete) by
+  // norm_missed_kernel right behind it -- the separate K4 pass over a second layout of |H|^2 is for the unfused form only.
   const int64_t lag = norm_lag_items(mp, F);
-  const int64_t n_fused = (fused && n_items > lag) ? n_items - lag : 0;
+  const int64_t n_fused = fused ? n_items : 0;
   if (n_fused > 0) {
     a.ff = bands ? nullptr : ffdtf; a.den = den; a.fuse_items = n_fused; a.lag = (int)lag;
     if (bands) {

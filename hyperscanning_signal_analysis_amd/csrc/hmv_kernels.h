@@ -72,15 +72,16 @@ struct TfArgs {
   int F, p, m;
   double tau;               // pivot threshold: 1.0 = LAPACK partial pivoting
   // ffDTF normalisation inside K3 (hot path only; ff == nullptr: off).  Items < fuse_items publish their |H|^2
-  // row-major and are normalised in-kernel, row i of item w by a workgroup of item w + lag; the caller runs K4
-  // on the items >= fuse_items.
+  // row-major; row i of item w < tail0 is normalised in-kernel by a workgroup of item w + lag, the rows of items
+  // tail0 .. fuse_items - 1 (the last `lag` of the batch) by norm_missed_kernel right behind K3; the caller runs K4
+  // on the items >= fuse_items (none on the hot path).
   double* ff;               // [n_items][m][m][F]
   double* den;              // [n_items][MP]
   int* wcount;              // [n_items] arrival counters          } one block of 2 * n_items + 1 ints that the
   int* ready;               // [n_items] denominators are in place  } launcher zeroes, followed by the list
   int* missed;              // [1 + fuse_items * MP] count, rows     } of rows left to norm_missed_kernel
   long long fuse_items;
-  int lag;
+  int lag;                  // (tail0 = max(0, fuse_items - lag): no field of its own -- the hand-scheduled K3 has no SGPR to spare)
   // reduced product (hot path, in-kernel normalisation only; bands == nullptr: off): instead of the ffDTF array the row
   // workers write its band sums, bands[item][i][j][b] = sum_{band_lo[b] <= f < band_hi[b]} ffdtf[item][i][j][f]
   // (the arithmetic of band_sums_stream_kernel, ffdtf_norm.hip: same partial sums, same tree, same bits); ff is unused

@@ -328,11 +328,24 @@ template <int NT>
 __global__ void __launch_bounds__(64 * NT) norm_missed_kernel(TfArgs a) {
   __shared__ double lds[2 * TfLds<NT>::TOTAL];           // as much as the row workers inside K3 have
   static_assert(NormLds<NT>::DOUBLES <= 2 * TfLds<NT>::TOTAL, "normaliser tiles do not fit");
+  // the rows that came up too early inside K3, then every row of the batch's last windows (items >= tail0: there is no
+  // later workgroup in the launch to take them; K3 has ended, so their windows are complete)
   const int n = a.missed[0];
-  for (int k = blockIdx.x; k < n; k += gridDim.x) {
-    const int e = a.missed[1 + k];
-    if (a.bands) band_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, 2 * TfLds<NT>::TOTAL, (int)threadIdx.x);
-    else normalise_row<NT>(a, e / (16 * NT), e % (16 * NT), lds, (int)threadIdx.x);
+  const long long tail0 = a.fuse_items > a.lag ? a.fuse_items - a.lag : 0;
+  const long long total = n + (a.fuse_items - tail0) * a.m;
+  for (long long k = blockIdx.x; k < total; k += gridDim.x) {
+    int item, i;
+    if (k < n) {
+      const int e = a.missed[1 + k];
+      item = e / (16 * NT);
+      i = e % (16 * NT);
+    } else {
+      const long long r = k - n;
+      item = (int)(tail0 + r / a.m);
+      i = (int)(r % a.m);
+    }
+    if (a.bands) band_row<NT>(a, item, i, lds, 2 * TfLds<NT>::TOTAL, (int)threadIdx.x);
+    else normalise_row<NT>(a, item, i, lds, (int)threadIdx.x);
     __syncthreads();
   }
 }
@@ -487,7 +500,7 @@ __device__ __forceinline__ void tf_outputs(const TfArgs& a, const int item, cons
       }
       // Rows f, f + F, ... of window item - lag are this workgroup's to normalise.
       const int wl = item - a.lag;
-      if (wl >= 0 && wl < a.fuse_items && f < a.m) {         // workgroup-uniform
+      if (wl >= 0 && wl < a.fuse_items - a.lag && f < a.m) { // workgroup-uniform (rows of the last `lag` fused items: norm_missed_kernel)
         __syncthreads();
         if (tid == 0) {
           // No acquire fence here (it costs ~7 us with four workgroups on the CU, 38 000 times per launch): the
@@ -1149,8 +1162,9 @@ int launch_tf_inv(const TfArgs& a_in, int m_pad, hipStream_t st) {
       break;
     default: return -1;
   }
-  if (fused) {          // rows whose window was not complete in time (normally none)
-    const dim3 mgrid(256);
+  if (fused) {          // rows whose window was not complete in time (normally none) and the rows of the last `lag` windows
+    const long long tail_rows = (a.fuse_items > a.lag ? a.lag : a.fuse_items) * a.m;
+    const dim3 mgrid((unsigned)(tail_rows > 2048 ? 2048 : (tail_rows < 256 ? 256 : tail_rows)));
     switch (m_pad) {
       case 16: hipLaunchKernelGGL(norm_missed_kernel<1>, mgrid, dim3(64), 0, st, a); break;
       case 32: hipLaunchKernelGGL(norm_missed_kernel<2>, mgrid, dim3(128), 0, st, a); break;

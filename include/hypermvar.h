@@ -187,10 +187,10 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
  * (:281-283).  K3 leaves |H|^2 and its row sums in `workspace` (write-through stores); the workgroup whose
  * matrix completes a window (device-scope arrival counter) adds up the row denominators, and the rows of that
  * window are turned into the output array by workgroups of a LATER window of the same launch while the rest of
- * the chip keeps inverting (nobody waits: a row whose window is not complete in time is done by a small kernel
- * after K3) -- the separate K4 pass only sees the last few windows of the batch.  Bit-identical to
- * hmv_tf_f64 + hmv_ffdtf_norm_f64.  Taken when F % 16 == 0 and ffdtf is 16-byte aligned, otherwise K4 does all
- * windows.  den: [item][MP] out; H (optional, may be NULL): complex128 [item][f][MP][MP] as from hmv_tf_f64 (what
+ * the chip keeps inverting (nobody waits: a row whose window is not complete in time, and the rows of the last few
+ * windows of the batch, which no later workgroup exists for, are done by a small kernel right behind K3).  Bit-identical
+ * to hmv_tf_f64 + hmv_ffdtf_norm_f64.  Taken when F % 16 == 0 and ffdtf is 16-byte aligned, otherwise the separate K4
+ * pass does all windows.  den: [item][MP] out; H (optional, may be NULL): complex128 [item][f][MP][MP] as from hmv_tf_f64 (what
  * hmv_spectra_f64 takes: ffDTF and spectra from one set of inverses); info: [item*F + f].
  * ev_k3_start / ev_k3_stop (optional hipEvent_t) are recorded on `stream` around the K3 launch. */
 int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F);
