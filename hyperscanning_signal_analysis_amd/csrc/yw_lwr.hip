@@ -38,11 +38,11 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
   constexpr int SI = YwCfg<NT>::S;
   constexpr int GEMM_D = 2 * MP * SH, INV_D = MP * SI, BUF_D = GEMM_D > INV_D ? GEMM_D : INV_D;
   __shared__ __attribute__((aligned(16))) double buf[BUF_D];
-  __shared__ double Pb[MP * 4];
-  __shared__ double Nb[2 * MP * 4];
+  __shared__ double Pb[2 * MP * 4];            // two panel and four N buffers: both inverses of an order at once
+  __shared__ double Nb[4 * MP * 4];
   __shared__ int s_info;
   __shared__ double s_ld[4];
-  __shared__ double s_pm[2 + 2 * 4];
+  __shared__ double s_pm[4 + 4 * 4];
   __shared__ int s_guard;
   double* Xh = buf;
   double* Yh = buf + MP * SH;
@@ -226,6 +226,15 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
     __syncthreads();            // the inverse is in global memory for the whole workgroup
   };
 
+  // both error covariances of an order inverted together (spd_inverse_coop2: their panels on different waves at the
+  // same time, one barrier per block step for the two)
+  auto invert2 = [&](const double (&ga)[NIW][NJ], const double (&gb)[NIW][NJ], double* out_a, double* out_b, double* logdet_b,
+                     int info_base) __attribute__((always_inline)) {
+    spd_inverse_coop2<NT, SI>(ga, gb, buf, Pb, Nb, &s_info, s_ld, out_a, out_b, logdet_b, info_base, s_pm);
+    if (threadIdx.x == 0 && (!(s_pm[0] >= HMV_LWR_GUARD * s_pm[1]) || !(s_pm[2] >= HMV_LWR_GUARD * s_pm[3]))) s_guard = 1;
+    __syncthreads();            // the inverses are in global memory for the whole workgroup
+  };
+
   double g[NIW][NJ], acc[NIW][NJ], dacc[NIW][NJ];
   const double (&none)[NIW][NJ] = g;
   // ---- order 0: Vf = Vb = C(0) = R_0 (symmetric), D_0 = C(1) = R_1^T
@@ -243,11 +252,20 @@ __global__ void __launch_bounds__(256, 3) yw_lwr_kernel(YwArgs a) {
     const bool last = (q == p - 1);
     // ---- inverses of the two error covariances of order q (log det Vf_q is the criterion's term of order q)
     load_tile(g, Vb, false);
-    invert(g, VbI, nullptr, q * MP);
+#ifndef HMV_LWR_SINGLE_INVERSES
     if (!last || (VQ && q >= 1)) {       // (the last order needs Vf^-1 only for its log det)
+      load_tile(acc, Vf, false);
+      invert2(g, acc, VbI, VfI, (VQ && q >= 1) ? a.Vq_logdet + (size_t)item * p + (q - 1) : nullptr, q * MP);
+    } else {
+      invert(g, VbI, nullptr, q * MP);
+    }
+#else
+    invert(g, VbI, nullptr, q * MP);
+    if (!last || (VQ && q >= 1)) {
       load_tile(g, Vf, false);
       invert(g, VfI, (VQ && q >= 1) ? a.Vq_logdet + (size_t)item * p + (q - 1) : nullptr, q * MP);
     }
+#endif
     // ---- A_{q+1} = D Vb^-1;  Vf <- Vf - A_{q+1} D^T
     zero(acc);
     product(acc, Dq, false, none, VbI, false);           // Vb^-1 is symmetric: X Y^T = D Vb^-1
