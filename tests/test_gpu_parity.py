@@ -375,6 +375,39 @@ def test_northstar_full_size_properties():
         assert_parity(ff[k].cpu().numpy(), ref)
 
 
+def test_config3_share_of_one_gpu_at_full_size():
+    """BASELINE config 3 (64 dyads x 10 min, dyad-sharded over 8 GPUs) as seen by ONE GPU: 8 ten-minute dyads = 4 792
+    windows of 64 channels, p = 8, 256 frequencies in one call, the reduced product (what is gathered over xGMI).
+    Size-independent checks on every window: the band that spans the whole grid sums to 1 over the columns of every row
+    (|.| <= 1e-12); a dyad gives the same bits wherever it sits in the batch and however the batch is chunked (one dyad
+    per chunk, four dyads per chunk); one window against the oracle."""
+    from hyperscanning_signal_analysis_amd import distributed as hdist
+    from hyperscanning_signal_analysis_amd.sliding import regular_grid, window_items, window_positions
+    eng = default_engine()
+    fs, w, p, T, D = 500.0, 1000, 8, 300_000, 8
+    freqs = northstar_freqs(256)
+    distinct = [synthetic_var_dyad(60 + d, T=T) for d in range(4)]
+    xd = eng.to_device(np.stack([distinct[d % 4] for d in range(D)]))           # dyads d and d + 4 are the same recording
+    pos, w = window_positions(T, 2 * T // w - 1, w)
+    nw = len(pos)
+    rec, st = window_items(D, pos, eng.device)
+    grid = regular_grid(pos, w, p)
+    lo, hi = hdist.band_bins(freqs)
+    lo, hi = list(lo) + [0], list(hi) + [256]                                     # + the whole grid as a sixth band
+    a = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, grid=grid, bands=(lo, hi), chunk=nw)
+    assert a.shape == (D * nw, 64, 64, 6) and bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0
+    assert float((a[..., 5].sum(dim=2) - 1).abs().max()) < 1e-12
+    av = a.view(D, nw, 64, 64, 6)
+    assert torch.equal(av[:4], av[4:])
+    b = eng.sliding_ffdtf(xd, rec, st, w, p, freqs, fs, grid=grid, bands=(lo, hi), chunk=4 * nw)
+    assert torch.equal(a, b)
+    del b
+    k = 311
+    ref = O.full_freq_dtf(distinct[2][:, pos[k]:pos[k] + w], freqs, fs, p)
+    want = np.stack([ref[..., l0:h0].sum(axis=-1) for l0, h0 in zip(lo, hi)], axis=-1)
+    assert_parity(av[6, k].cpu().numpy(), want)
+
+
 def test_two_stream_overlap_is_bit_identical():
     """K2 split into two half-batches on two HIP streams (fork/join inside the fused C call), and chunking of
     the windows, give the same bits as one stream / one chunk."""
