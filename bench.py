@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "C2"): per GPU ONE synthetic dyad,
 2 x 32 channels @ 500 Hz, 10 minutes (T = 300 000), 2 s windows with 50 % overlap (599 windows),
 MVAR order p = 8, 256-point frequency grid 0.5 .. 128 Hz, float64.  One "step" = one pass of the hot path
-(K1 lag covariance -> K2 Yule-Walker -> K3 transfer inverse + |H|^2 + ffDTF normalisation; K4 only for the
-last windows of the batch) over those windows, input already resident in HBM, output left in HBM as
+(K1 lag covariance -> K2 Yule-Walker -> K3 transfer inverse + |H|^2 + ffDTF normalisation, the rows of the
+last windows of the batch by a small kernel right behind it) over those windows, input already resident in HBM, output left in HBM as
 (windows, 64, 64, 256) float64.
 `--dyads-per-gpu D` puts D dyads on every GPU (D x 599 windows per step, processed in chunks of one dyad);
 `--gpus 8 --dyads-per-gpu 8` is BASELINE.json configs[2] ("C3": 64 dyads, dyad-sharded across 8 GPUs).
