@@ -160,7 +160,7 @@ def prepare_dyad(dyad, files_by_task, reader, low_cutoff_hz=None, high_cutoff_hz
 def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, freqs=None, bands=hdist.DEFAULT_BANDS,
         low_cutoff_hz=None, high_cutoff_hz=None, channel_subset=None, with_psd=False, psd_fmin=1.0, psd_fmax=30.0,
         psd_bandwidth=2.0, save_full=False, skip_existing=True, reader=None, engine=None, world=1, rank=0,
-        verbose=True, prefetch=2, timing=None):
+        verbose=True, prefetch=2, timing=None, save_workers=8):
     """Process every dyad under <root>/EEG.  Per dyad one `<out_dir>/<dyad>_ffdtf.npz` with, per segment `<task>/<event>`:
         <seg>/ffdtf_bands   (windows, n, n, n_bands)   band-integrated ffDTF of every window
         <seg>/ffdtf         (windows, n, n, F)         only with save_full=True (8.4 MB per window at 64 channels)
@@ -196,7 +196,10 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
     tm = {"wall_s": 0.0, "host_prepare_s": 0.0, "wait_for_host_s": 0.0, "gpu_s": 0.0, "save_s": 0.0, "dyads": []}
     t_all = time.perf_counter()
     psd_stream = torch.cuda.Stream(eng.device) if with_psd else None
-    pool = cf.ThreadPoolExecutor(max_workers=max(2, int(prefetch) + 1))
+    # two pools: the compressed writes (2 - 3 s of zlib per full-size dyad) must not take the workers that prepare the
+    # next dyads, or the GPU waits for its input behind somebody's output
+    pool = cf.ThreadPoolExecutor(max_workers=max(1, int(prefetch)))
+    save_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(save_workers)))
     futures, saves = {}, []
 
     def submit(k):
@@ -241,13 +244,17 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                             with torch.cuda.stream(psd_stream):
                                 pf, psd_dev = compute_psd_multitaper_device(xd[0], fs, psd_fmin, psd_fmax, psd_bandwidth, engine=eng)
                             xd.record_stream(psd_stream)
-                        ff, bad = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="mask",
-                                                    grid=regular_grid(pos, W, int(model_order)))
                         lo, hi = hdist.band_bins(f, bands)
-                        bsum = eng.band_sums(ff, lo, hi)
-                        bsum.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
+                        grid_w = regular_grid(pos, W, int(model_order))
                         if save_full:
+                            ff, bad = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="mask", grid=grid_w)
+                            bsum = eng.band_sums(ff, lo, hi)
                             ff.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
+                        else:          # the reduced product straight from K3's row workers: the full array is never written
+                            ff = None
+                            bsum, bad = eng.sliding_ffdtf(xd, rec_i, st_i, W, int(model_order), f, fs, check="mask",
+                                                          grid=grid_w, bands=(lo, hi))
+                        bsum.masked_fill_(bad.view(-1, 1, 1, 1), float("nan"))
                         pending.append((seg, key, pos, W, f, bsum, ff if save_full else None, bad, psd_dev, pf if with_psd else None))
                     except Exception as e:                         # one bad segment does not discard the dyad
                         meta["failed_segments"].append({"segment": key, "error": f"{type(e).__name__}: {e}"})
@@ -284,7 +291,7 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                                         bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
                     tmp.replace(target)                       # a file that exists is complete (skip-if-exists relies on it)
                     return time.perf_counter() - t0
-                saves.append((dyad, target, pool.submit(_save)))
+                saves.append((dyad, target, save_pool.submit(_save)))
                 save_s = 0.0
                 done.append(dyad)
                 tm["host_prepare_s"] += prep["host_s"]; tm["wait_for_host_s"] += wait_s
@@ -305,6 +312,7 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                 say(f"Failed: {dyad} -> {e}")
     finally:
         pool.shutdown(wait=True, cancel_futures=True)
+        save_pool.shutdown(wait=True)
     tm["wall_s"] = time.perf_counter() - t_all
     tm["gpu_busy_fraction_of_wall"] = tm["gpu_s"] / tm["wall_s"] if tm["wall_s"] > 0 else 0.0
     if timing is not None:

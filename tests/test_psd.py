@@ -34,8 +34,13 @@ def test_oracle_properties_cpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ch,n,fs,bw", [(5, 6000, 500.0, 2.0), (19, 4097, 128.0, 1.0), (2, 30_001, 500.0, 2.0)])
+@pytest.mark.parametrize("n_ch,n,fs,bw", [(5, 6000, 500.0, 2.0), (19, 4097, 128.0, 1.0), (2, 30_001, 500.0, 2.0),
+                                           (4, 20_011, 500.0, 2.0), (3, 4100, 250.0, 3.0)])
 def test_gpu_psd_matches_restatement(n_ch, n, fs, bw):
+    """Lengths whose prime factors are all <= 13 go through batched real-to-complex FFTs; the others (4 097 = 17 * 241,
+    20 011 prime, 4 100 = 4 * 25 * 41: a segment cut by event times has any length) through the pruned chirp-z transform
+    of csrc/psd.hip when the wanted band is narrow enough (two tapers per complex transform, an odd taper count leaves the
+    last one half empty), else through rocFFT's own Bluestein (30 001): the same numbers on the same bins."""
     from hyperscanning_signal_analysis_amd.psd import compute_psd_multitaper
     x, _ = _signal(n_ch, n, fs, seed=n_ch)
     freqs, psd = compute_psd_multitaper(x, fs, 1.0, 30.0, bw)
@@ -57,6 +62,13 @@ def test_gpu_psd_chunked_channels_and_edges():
     assert np.allclose(average_psd_across_conditions({"a": p1, "b": 3 * p1}), 2 * p1)
     with pytest.raises(ValueError):
         average_psd_across_conditions({})
+    # the same on the chirp-z path (4 100 samples): the DC bin included, one channel per chunk, run twice (cached tables)
+    x, fs = _signal(5, 4100, 250.0, seed=10)
+    f3, p3 = compute_psd_multitaper(x, fs, 0.0, 20.0, 2.0)
+    f4, p4 = compute_psd_multitaper(x, fs, 0.0, 20.0, 2.0, max_workspace_bytes=1)
+    fo, po = P.compute_psd_multitaper(x, fs, 0.0, 20.0, 2.0)
+    assert f3[0] == 0.0 and np.array_equal(p3, p4) and np.array_equal(f3, fo)
+    assert np.abs(p3 - po).max() <= 1e-9 * np.abs(po).max()
 
 
 @pytest.mark.gpu
