@@ -37,7 +37,7 @@ from .eeg_io import filter_eeg
 from .engine import default_engine
 from .sliding import hop_positions, regular_grid, window_items
 
-__all__ = ["discover_dyads", "decode_events", "segment_block", "prepare_dyad", "run", "xarray_reader"]
+__all__ = ["discover_dyads", "decode_events", "segment_block", "prepare_dyad", "run", "savez_fast", "xarray_reader"]
 
 ROLES = (("ch", "child"), ("cg", "caregiver"))
 _FILE_RE = re.compile(r"^(?P<dyad>.+)_EEG_(?P<role>ch|cg)_(?P<task>.+)$")
@@ -157,10 +157,24 @@ def prepare_dyad(dyad, files_by_task, reader, low_cutoff_hz=None, high_cutoff_hz
     return {"segments": segs, "notes": notes, "host_s": time.perf_counter() - t0}
 
 
+def savez_fast(path, compresslevel=0, **arrays):
+    """np.savez / np.savez_compressed with a choice of deflate level (same .npz container, np.load reads it).  float64
+    connectivity values do not compress -- 5 % at NumPy's fixed level 6 (88.8 of 94.2 MB for the band sums of one
+    full-size dyad) for 3.9 s of a host core, more than the dyad's preprocessing and 100x its GPU time; level 1 is hardly
+    faster (3.4 s).  0 = stored (default), 1..9 = deflate."""
+    import zipfile
+    method = zipfile.ZIP_STORED if int(compresslevel) <= 0 else zipfile.ZIP_DEFLATED
+    kw = {} if method == zipfile.ZIP_STORED else {"compresslevel": int(compresslevel)}
+    with zipfile.ZipFile(path, mode="w", compression=method, allowZip64=True, **kw) as zf:
+        for key, val in arrays.items():
+            with zf.open(key + ".npy", mode="w", force_zip64=True) as f:
+                np.lib.format.write_array(f, np.asanyarray(val), allow_pickle=False)
+
+
 def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, freqs=None, bands=hdist.DEFAULT_BANDS,
         low_cutoff_hz=None, high_cutoff_hz=None, channel_subset=None, with_psd=False, psd_fmin=1.0, psd_fmax=30.0,
         psd_bandwidth=2.0, save_full=False, skip_existing=True, reader=None, engine=None, world=1, rank=0,
-        verbose=True, prefetch=2, timing=None, save_workers=8):
+        verbose=True, prefetch=2, timing=None, save_workers=4, compresslevel=0):
     """Process every dyad under <root>/EEG.  Per dyad one `<out_dir>/<dyad>_ffdtf.npz` with, per segment `<task>/<event>`:
         <seg>/ffdtf_bands   (windows, n, n, n_bands)   band-integrated ffDTF of every window
         <seg>/ffdtf         (windows, n, n, F)         only with save_full=True (8.4 MB per window at 64 channels)
@@ -196,7 +210,7 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
     tm = {"wall_s": 0.0, "host_prepare_s": 0.0, "wait_for_host_s": 0.0, "gpu_s": 0.0, "save_s": 0.0, "dyads": []}
     t_all = time.perf_counter()
     psd_stream = torch.cuda.Stream(eng.device) if with_psd else None
-    # two pools: the compressed writes (2 - 3 s of zlib per full-size dyad) must not take the workers that prepare the
+    # two pools: the writes (3 - 4 s of zlib per full-size dyad when compressed) must not take the workers that prepare the
     # next dyads, or the GPU waits for its input behind somebody's output
     pool = cf.ThreadPoolExecutor(max_workers=max(1, int(prefetch)))
     save_pool = cf.ThreadPoolExecutor(max_workers=max(1, int(save_workers)))
@@ -282,13 +296,13 @@ def run(root, out_dir, tasks=None, window_s=2.0, overlap=0.5, model_order=8, fre
                     say(f"[SKIP] {dyad}: no complete child + caregiver segment")
                     skipped.append(dyad)
                     continue
-                # the compressed write (2 - 3 s per full-size dyad, zlib outside the GIL) goes to the worker pool as well:
-                # the GPU and the next dyad's host work do not wait for it
+                # the write goes to a worker pool of its own (stored by default; deflate -- compresslevel > 0 -- costs 3 - 4 s of
+                # a core per full-size dyad, zlib outside the GIL): the GPU and the next dyad's host work do not wait for it
                 def _save(target=target, names_out=names_out, freqs_out=freqs_out, meta=meta, result=result):
                     t0 = time.perf_counter()
                     tmp = target.with_suffix(".tmp.npz")
-                    np.savez_compressed(tmp, channels=np.asarray(names_out), freqs=freqs_out,
-                                        bands=np.asarray(bands, dtype=np.float64), meta=json.dumps(meta), **result)
+                    savez_fast(tmp, compresslevel, channels=np.asarray(names_out), freqs=freqs_out,
+                               bands=np.asarray(bands, dtype=np.float64), meta=np.asarray(json.dumps(meta)), **result)
                     tmp.replace(target)                       # a file that exists is complete (skip-if-exists relies on it)
                     return time.perf_counter() - t0
                 saves.append((dyad, target, save_pool.submit(_save)))
