@@ -185,7 +185,7 @@ long long czt_length(long long n, long long hi) {  // 0: the plain transform is 
   while (L < n + 2 * hi + 1) L <<= 1;
   long long LB = 1;                                // what Bluestein would take
   while (LB < 2 * n - 1) LB <<= 1;
-  return (2 * L <= LB) ? L : 0;
+  return (L <= LB) ? L : 0;        // (two tapers per transform: ahead even at Bluestein's own length)
 }
 hipfftHandle zplan(long long L, int batch) {
   auto it = g_zplans.find({L, batch});
@@ -200,8 +200,14 @@ hipfftHandle zplan(long long L, int batch) {
 
 long long psd_workspace_bytes(long long ch_chunk, long long n, int K) {
   const long long nfreq = n / 2 + 1;
-  // (+ 4 n per channel: the chirp-z path packs ceil(K / 2) complex rows of up to 2 n points)
-  return (long long)sizeof(double) * (ch_chunk * K * n + 2 * ch_chunk * K * nfreq + 4 * ch_chunk * n + ch_chunk + 64);
+  long long body = ch_chunk * K * n + 2 * ch_chunk * K * nfreq;          // y and X of the plain path (doubles)
+  if (!smooth_length(n)) {      // the chirp-z path: ceil(K / 2) complex rows of up to Bluestein's own length per channel
+    long long LB = 1;
+    while (LB < 2 * n - 1) LB <<= 1;
+    const long long czt = 2 * ch_chunk * ((K + 1) / 2) * LB;
+    if (czt > body) body = czt;
+  }
+  return (long long)sizeof(double) * (body + ch_chunk + 64);
 }
 
 int launch_psd(const double* x, long long n_ch, long long n, long long ld, const double* tapers, const double* w, int K,
@@ -212,7 +218,7 @@ int launch_psd(const double* x, long long n_ch, long long n, long long ld, const
   double* mean = reinterpret_cast<double*>(base);
   if (const long long L = czt_length(n, hi)) {
     const int P = (K + 1) / 2;
-    // the chunk's buffer holds ch_chunk * K * n doubles + 2 * ch_chunk * K * nfreq: at least ch_chunk * P * L double2 (L < 2 n)
+    // (psd_workspace_bytes covers ch_chunk * P rows of L <= Bluestein's length)
     CztPlan pl;
     {
       std::lock_guard<std::mutex> lock(g_plan_mutex);
