@@ -187,6 +187,24 @@ long long czt_length(long long n, long long hi) {  // 0: the plain transform is 
   while (LB < 2 * n - 1) LB <<= 1;
   return (L <= LB) ? L : 0;        // (two tapers per transform: ahead even at Bluestein's own length)
 }
+// A batch over many recordings meets a new segment length with almost every file: the caches are bounded (plans carry
+// device work buffers), oldest-first is not worth the bookkeeping -- past the bound everything goes and is rebuilt.
+constexpr size_t kMaxCached = 24;
+void trim_caches(hipStream_t st) {                 // g_plan_mutex held
+  if (g_plans.size() + g_zplans.size() <= kMaxCached && g_czt.size() <= kMaxCached) return;
+  (void)st;
+  (void)hipDeviceSynchronize();                    // nothing in flight, on any stream, uses them (rare: once per 24 lengths)
+  for (auto& kv : g_plans) hipfftDestroy(kv.second);
+  for (auto& kv : g_zplans) hipfftDestroy(kv.second);
+  for (auto& kv : g_czt) {
+    (void)hipFree(kv.second.chirp);
+    (void)hipFree(kv.second.bf);
+    (void)hipFree(kv.second.eout);
+  }
+  g_plans.clear();
+  g_zplans.clear();
+  g_czt.clear();
+}
 hipfftHandle zplan(long long L, int batch) {
   auto it = g_zplans.find({L, batch});
   if (it != g_zplans.end()) return it->second;
@@ -216,6 +234,10 @@ int launch_psd(const double* x, long long n_ch, long long n, long long ld, const
   const long long nfreq = n / 2 + 1, nb = hi - lo + 1;
   char* base = static_cast<char*>(workspace);
   double* mean = reinterpret_cast<double*>(base);
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    trim_caches(st);
+  }
   if (const long long L = czt_length(n, hi)) {
     const int P = (K + 1) / 2;
     // (psd_workspace_bytes covers ch_chunk * P rows of L <= Bluestein's length)

@@ -110,3 +110,22 @@ def test_gpu_dpss_refuses_bad_arguments_and_psd_uses_device_tapers(tmp_path, mon
     P._TAPERS.clear()                          # second call: tapers from the file
     f2, p2 = P.compute_psd_multitaper(x, 250.0, 1.0, 40.0, 2.0)
     assert np.array_equal(f1, f2) and np.array_equal(p1, p2)
+
+
+@pytest.mark.gpu
+def test_gpu_psd_many_segment_lengths_bounded_caches():
+    """A batch meets a new segment length with almost every file: FFT plans and chirp-z tables are cached up to a bound and
+    rebuilt past it.  30 lengths (smooth and awkward alternating), each against the restatement, the first one again at the
+    end (its plan and tables were dropped in between)."""
+    from hyperscanning_signal_analysis_amd.psd import compute_psd_multitaper
+    first = None
+    for k in range(30):
+        n = 2000 + 37 * k + (k % 2)
+        x, fs = _signal(2, n, 250.0, seed=100 + k)
+        f, p = compute_psd_multitaper(x, fs, 1.0, 30.0, 2.0)
+        fo, po = P.compute_psd_multitaper(x, fs, 1.0, 30.0, 2.0)
+        assert np.array_equal(f, fo) and np.abs(p - po).max() <= 1e-9 * np.abs(po).max(), n
+        if first is None:
+            first = (x, fs, p)
+    f, p = compute_psd_multitaper(first[0], first[1], 1.0, 30.0, 2.0)
+    assert np.array_equal(p, first[2])
