@@ -144,6 +144,20 @@ def test_streamed_recordings_equal_resident_ones(pinned):
         assert got[d].shape == want.shape == (len(pos), m, m, len(hdist.DEFAULT_BANDS))
         assert np.array_equal(got[d], want, equal_nan=True), d
         assert np.isnan(want).all() == (d == 3)
+    # other pipeline depths (1: strictly serial, the download of d queued before d + 1 starts; 3: the default), a consumer of
+    # the full array on the device (keep_full: then the bands are summed from the array, the two-kernel route) and a
+    # caller-chosen reduction: the same numbers
+    for kw in ({"depth": 1}, {}, {"keep_full": lambda d, ff: seen.append((d, tuple(ff.shape)))},
+               {"reduce": lambda ff: ff.sum(dim=3)}):
+        seen = []
+        again = eng.stream_dyads(feed, n, pos, p, freqs, 500.0, **kw)
+        for d in range(5):
+            if "reduce" in kw:
+                assert again[d].shape == (len(pos), m, m) and (d == 3 or np.allclose(again[d].sum(axis=2), 1.0, atol=1e-12))
+            else:
+                assert np.array_equal(again[d], got[d], equal_nan=True), (kw, d)
+        if "keep_full" in kw:
+            assert seen == [(d, (len(pos), m, m, len(freqs))) for d in range(5)]
 
 
 def _npz_equal(a, b):
