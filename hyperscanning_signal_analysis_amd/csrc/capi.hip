@@ -385,14 +385,7 @@ int tf_ffdtf_impl(const char* who, const double* ar, int64_t n_items, int m, int
   a.stamps = g_tf_stamps;
 #endif
   hipStream_t st = S(stream);
-  int rc = 0;
-  if (ev_k3_start) rc = (int)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_start), st);
-  if (rc) return rc;
-  rc = hmv::launch_tf_inv(a, mp, st);
-  if (ev_k3_stop) {
-    const int erc = (int)hipEventRecord(reinterpret_cast<hipEvent_t>(ev_k3_stop), st);
-    if (!rc) rc = erc;
-  }
+  int rc = hmv::launch_tf_inv(a, mp, st, reinterpret_cast<hipEvent_t>(ev_k3_start), reinterpret_cast<hipEvent_t>(ev_k3_stop));
   if (rc) return rc;
   if (n_fused < n_items) {
     const int64_t n_tail = n_items - n_fused;

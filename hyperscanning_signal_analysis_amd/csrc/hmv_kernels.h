@@ -92,7 +92,7 @@ struct TfArgs {
   unsigned long long* stamps;   // diagnostic builds (-DHMV_STAMP) only: [wave][8] phase cycle sums; else null
 };
 int launch_twiddles(const double* freqs, int F, double fs, int p, double* tw, hipStream_t st);
-int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st);
+int launch_tf_inv(const TfArgs& a, int m_pad, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 int launch_cinv(const TfArgs& a, int m_pad, hipStream_t st);
 long long tf_workspace_doubles(long long n_items, int m_pad, int p);
 int tf_band_max_F(int m_pad);

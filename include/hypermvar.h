@@ -192,7 +192,8 @@ int hmv_psd_multitaper_f64(const double* x, int64_t n_ch, int64_t n_times, int64
  * to hmv_tf_f64 + hmv_ffdtf_norm_f64.  Taken when F % 16 == 0 and ffdtf is 16-byte aligned, otherwise the separate K4
  * pass does all windows.  den: [item][MP] out; H (optional, may be NULL): complex128 [item][f][MP][MP] as from hmv_tf_f64 (what
  * hmv_spectra_f64 takes: ffDTF and spectra from one set of inverses); info: [item*F + f].
- * ev_k3_start / ev_k3_stop (optional hipEvent_t) are recorded on `stream` around the K3 launch. */
+ * ev_k3_start / ev_k3_stop (optional hipEvent_t) are recorded on `stream` right before and after the K3 kernel itself
+ * (not the coefficient-packing kernel in front of it, not the small kernel behind it). */
 int64_t hmv_tf_ffdtf_workspace_bytes(int64_t n_items, int m, int p, int F);
 int hmv_tf_ffdtf_f64(const double* ar, int64_t n_items, int m, int p, const double* tw, int F,
                      double* ffdtf, double* den, double* H, int32_t* info, double pivot_tau,
