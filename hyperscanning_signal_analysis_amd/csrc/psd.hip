@@ -128,13 +128,16 @@ __global__ void __launch_bounds__(256) czt_pack_kernel(const double* x, long lon
   }
   a[((size_t)ch * P + pr) * L + t] = v;
 }
-// A[row][l] *= bf[l]; grid (ceil(L / 256), rows)
-__global__ void __launch_bounds__(256) czt_mul_kernel(double2* A, const double2* bf, long long L) {
+// A[row][l] *= bf[l]; grid (ceil(L / 256), min(rows, 32768)): rows may exceed the 65 535 of a grid's second dimension
+__global__ void __launch_bounds__(256) czt_mul_kernel(double2* A, const double2* bf, long long L, long long rows) {
   const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
   if (l >= L) return;
-  double2* p = A + (size_t)blockIdx.y * L + l;
-  const double2 u = *p, v = bf[l];
-  *p = make_double2(u.x * v.x - u.y * v.y, u.x * v.y + u.y * v.x);
+  const double2 v = bf[l];
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+    double2* p = A + (size_t)r * L + l;
+    const double2 u = *p;
+    *p = make_double2(u.x * v.x - u.y * v.y, u.x * v.y + u.y * v.x);
+  }
 }
 // psd[ch][b] from the convolution outputs C[(ch * P + pr)][m], m = j + hi;  grid (ceil(nb / 256), channels of the chunk)
 __global__ void __launch_bounds__(256) czt_power_kernel(const double2* C, const double2* eout, const double* w, long long L,
@@ -278,7 +281,8 @@ int launch_psd(const double* x, long long n_ch, long long n, long long ld, const
         if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return -21;
         hipfftDoubleComplex* Az = reinterpret_cast<hipfftDoubleComplex*>(A);
         if (hipfftExecZ2Z(plan, Az, Az, HIPFFT_FORWARD) != HIPFFT_SUCCESS) return -22;
-        hipLaunchKernelGGL(czt_mul_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)batch), dim3(256), 0, st, A, pl.bf, L);
+        hipLaunchKernelGGL(czt_mul_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)(batch < 32768 ? batch : 32768)), dim3(256), 0, st,
+                           A, pl.bf, L, (long long)batch);
         if (hipfftExecZ2Z(plan, Az, Az, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return -22;
       }
       hipLaunchKernelGGL(czt_power_kernel, dim3((unsigned)((nb + 255) / 256), (unsigned)c), dim3(256), 0, st, A, pl.eout, w, L, n,
