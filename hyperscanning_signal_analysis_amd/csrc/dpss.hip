@@ -40,14 +40,26 @@ struct DpssMat {
   __device__ __forceinline__ double e(long long i) const { return 0.5 * (double)(i + 1) * (double)(M - 1 - i); }
 };
 
-// number of eigenvalues < x  (LAPACK dstebz / dlaebz recurrence)
+// number of eigenvalues < x  (LAPACK dstebz / dlaebz recurrence).  110 000 dependent steps per probe, eleven rounds of
+// probes: what a step costs is what the kernel costs.  d_i and e_i come from running values (h -= 1, i + 1 += 1,
+// M - 1 - i -= 1: small integers and half-integers, exact in double, so the SAME numbers as the closed forms), and the
+// quotient e^2 / q is e^2 * (1 / q) with the hardware reciprocal and one Newton step (~1e-16 relative: it moves a Sturm
+// count only where q is within rounding of zero, i.e. it perturbs the probe by an ulp) instead of the ~15-instruction
+// IEEE division: 120 -> ~50 ms at 110 000 points.
 __device__ __forceinline__ long long sturm_count(const DpssMat& T, double x, double pivmin) {
-  double q = T.d(0) - x;
+  double h = 0.5 * (double)(T.M - 1);               // (M - 1 - 2 i) / 2
+  double fi = 1.0, gi = (double)(T.M - 1);          // i + 1, M - 1 - i
+  double q = h * h * T.c2w - x;
   if (fabs(q) < pivmin) q = -pivmin;
   long long c = q < 0.0 ? 1 : 0;
   for (long long i = 1; i < T.M; ++i) {
-    const double ee = T.e(i - 1);
-    q = T.d(i) - x - ee * ee / q;
+    const double ee = 0.5 * fi * gi;                // e(i - 1)
+    h -= 1.0;
+    fi += 1.0;
+    gi -= 1.0;
+    double r = __builtin_amdgcn_rcp(q);
+    r = __builtin_fma(__builtin_fma(-q, r, 1.0), r, r);
+    q = h * h * T.c2w - x - ee * ee * r;
     if (fabs(q) < pivmin) q = -pivmin;
     c += q < 0.0 ? 1 : 0;
   }
@@ -76,141 +88,243 @@ __global__ void __launch_bounds__(64) dpss_bisect_kernel(DpssMat T, int K, doubl
   if (t == 0) lam[k] = 0.5 * (lo + hi);
 }
 
-// One thread per eigenvector.  Arrays are [i][KP] (eigenvector index fastest).  Follows LAPACK dlagtf / dlagts(job=-1)
-// as used by dstein: LU of T - lambda I with row interchanges between neighbours, then x <- (T - lambda I)^-1 x with
-// tiny pivots perturbed, three times, the iterate rescaled before every solve.  Only a handful of waves run, so
-// nothing hides memory latency: the recurrences are walked in blocks of DB steps whose loads are all issued first.
-constexpr int DB = 16;
-__global__ void __launch_bounds__(64) dpss_invit_kernel(DpssMat T, int K, int KP, const double* lam, double onenrm, double eps,
-                                                        double* a, double* b, double* c, double* dd, unsigned char* in,
-                                                        double* x) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+// One WAVE per eigenvector.  The arithmetic is LAPACK's dlagtf / dlagts(job = -1) as dstein uses them -- LU of T - lambda I
+// with row interchanges between neighbours, then x <- (T - lambda I)^-1 x with tiny pivots perturbed, three times, the
+// iterate rescaled before every solve -- i.e. first-order recurrences: nothing to parallelise inside one vector.  The
+// first version ran one THREAD per vector over [i][k] arrays: ~440 threads = 7 waves on the whole chip, every block of
+// 16 steps waiting ~2 us for its loads with nothing to hide them: 198 ms for 110 000 points.  Here every vector has a
+// wave of its own (440 chains on 440 SIMDs): the 64 lanes fetch the next block of BL points of every array with coalesced
+// loads ([k][i] arrays) while the recurrence walks the current block out of LDS, and store the finished block the same
+// way; all lanes run the (uniform) recurrence, lane 0 writes.  Same operations in the same order per vector: same bits.
+constexpr int BL = 256, DB = 16;
+__global__ void __launch_bounds__(64) dpss_invit_kernel(DpssMat T, int K, const double* lam, double onenrm, double eps, double* a,
+                                                        double* b, double* c, double* dd, unsigned char* in, double* x) {
+  __shared__ double s_in[2][4][BL];          // double-buffered inputs of a block (x / a / b / d, or x / c / flag)
+  __shared__ double s_out[5][BL];            // the block's results
+  const int k = blockIdx.x, l = threadIdx.x;
   if (k >= K) return;
   const long long n = T.M;
   const double lambda = lam[k];
-  auto at = [&](long long i) { return (size_t)i * KP + k; };
+  double* ak_ = a + (size_t)k * n;
+  double* bk_ = b + (size_t)k * n;
+  double* ck_ = c + (size_t)k * n;
+  double* dk_ = dd + (size_t)k * n;
+  unsigned char* ik_ = in + (size_t)k * n;
+  double* xk_ = x + (size_t)k * n;
+  auto wsync = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
   // ---- dlagtf (d_i, e_i from their closed forms: this pass only stores)
   double tol = 0.0, alast = 0.0;
   {
     double ak = T.d(0) - lambda;                                   // a[i] of the running elimination
     double bk = n > 1 ? T.e(0) : 0.0;                              // b[i] (superdiagonal), may be rewritten by an interchange
     double scale1 = fabs(ak) + fabs(bk);
-    for (long long i = 0; i + 1 < n; ++i) {
-      const double ci = T.e(i);                                    // subdiagonal c[i]
-      double a1 = T.d(i + 1) - lambda;                             // a[i+1]
-      double b1 = (i + 2 < n) ? T.e(i + 1) : 0.0;                  // b[i+1]
-      const double scale2 = fabs(ci) + fabs(a1) + ((i + 2 < n) ? fabs(b1) : 0.0);
-      const double piv1 = (ak == 0.0) ? 0.0 : fabs(ak) / scale1;
-      double astore = ak, bstore = bk, cstore = 0.0, dstore = 0.0;
-      unsigned char flag = 0;
-      if (ci == 0.0) {
-        scale1 = scale2;
-      } else {
-        const double piv2 = fabs(ci) / scale2;
-        if (piv2 <= piv1) {                                        // no interchange
+    for (long long i0 = 0; i0 + 1 < n; i0 += BL) {
+      const int cnt = (int)((n - 1 - i0 < BL) ? (n - 1 - i0) : BL);
+      for (int u = 0; u < cnt; ++u) {
+        const long long i = i0 + u;
+        const double ci = T.e(i);                                    // subdiagonal c[i]
+        double a1 = T.d(i + 1) - lambda;                             // a[i+1]
+        double b1 = (i + 2 < n) ? T.e(i + 1) : 0.0;                  // b[i+1]
+        const double scale2 = fabs(ci) + fabs(a1) + ((i + 2 < n) ? fabs(b1) : 0.0);
+        double astore = ak, bstore = bk, cstore = 0.0, dstore = 0.0;
+        double flag = 0.0;
+        if (ci == 0.0) {
           scale1 = scale2;
-          cstore = ci / ak;
-          a1 -= cstore * bk;
-        } else {                                                   // rows i and i+1 change places
-          flag = 1;
-          const double mult = ak / ci;
-          astore = ci;
-          const double temp = a1;
-          a1 = bk - mult * temp;
-          if (i + 2 < n) {
-            dstore = b1;
-            b1 = -mult * dstore;
+        } else {
+          // dlagtf compares piv2 = |c_i| / scale2 with piv1 = |a| / scale1 (0 if a == 0): the same decision from the
+          // cross products (both scales are positive), two divisions fewer on a 110 000-step dependent chain; the two forms
+          // can differ only when the candidates tie to rounding, where either pivot is as good
+          if (fabs(ci) * scale1 <= fabs(ak) * scale2) {              // no interchange
+            scale1 = scale2;
+            cstore = ci / ak;
+            a1 -= cstore * bk;
+          } else {                                                   // rows i and i+1 change places
+            flag = 1.0;
+            const double mult = ak / ci;
+            astore = ci;
+            const double temp = a1;
+            a1 = bk - mult * temp;
+            if (i + 2 < n) {
+              dstore = b1;
+              b1 = -mult * dstore;
+            }
+            bstore = temp;
+            cstore = mult;
           }
-          bstore = temp;
-          cstore = mult;
         }
+        if (l == 0) {
+          s_out[0][u] = astore; s_out[1][u] = bstore; s_out[2][u] = cstore; s_out[3][u] = dstore; s_out[4][u] = flag;
+        }
+        tol = fmax(tol, fmax(fabs(astore), fmax(fabs(bstore), fabs(dstore))));      // dlagts' tolerance: largest factor entry
+        ak = a1;
+        bk = b1;
       }
-      a[at(i)] = astore; b[at(i)] = bstore; c[at(i)] = cstore; dd[at(i)] = dstore; in[at(i)] = flag;
-      tol = fmax(tol, fmax(fabs(astore), fmax(fabs(bstore), fabs(dstore))));      // dlagts' tolerance: largest factor entry
-      ak = a1;
-      bk = b1;
+      wsync();
+      for (int u = l; u < cnt; u += 64) {
+        ak_[i0 + u] = s_out[0][u]; bk_[i0 + u] = s_out[1][u]; ck_[i0 + u] = s_out[2][u]; dk_[i0 + u] = s_out[3][u];
+        ik_[i0 + u] = (unsigned char)(s_out[4][u] != 0.0);
+      }
+      wsync();
     }
-    a[at(n - 1)] = ak;
+    if (l == 0) ak_[n - 1] = ak;
     alast = fabs(ak);
     tol = fmax(tol, alast) * eps;
     if (tol == 0.0) tol = eps;
   }
   // ---- start vector: fixed pseudo-random numbers in (-1, 1) (dstein: dlarnv uniform(-1, 1))
   double xmax = 0.0;
-  unsigned long long s = 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1);
-  for (long long i = 0; i < n; ++i) {
-    s = s * 6364136223846793005ull + 1442695040888963407ull;
-    const double v = (double)(long long)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0;
-    x[at(i)] = v;
-    xmax = fmax(xmax, fabs(v));
+  {
+    unsigned long long s = 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1);
+    for (long long i0 = 0; i0 < n; i0 += BL) {
+      const int cnt = (int)((n - i0 < BL) ? (n - i0) : BL);
+      for (int u = 0; u < cnt; ++u) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const double v = (double)(long long)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        if (l == 0) s_out[0][u] = v;
+        xmax = fmax(xmax, fabs(v));
+      }
+      wsync();
+      for (int u = l; u < cnt; u += 64) xk_[i0 + u] = s_out[0][u];
+      wsync();
+    }
   }
+  __threadfence_block();
   for (int it = 0; it < 3; ++it) {
     // scale the iterate as dstein does: |x|_max -> n * onenrm * max(eps, |a[n-1]|)
     const double scl = (double)n * onenrm * fmax(eps, alast) / xmax;
-    // ---- dlagts, job = -1: forward substitution with the interchanges (the rescaling folded in)
-    double yprev = x[at(0)] * scl;
-    for (long long i0 = 1; i0 < n; i0 += DB) {
-      double xv[DB], cv[DB];
-      unsigned char fv[DB];
+    // ---- dlagts, job = -1: forward substitution with the interchanges (the rescaling folded in).  Step i (1 .. n-1)
+    // reads x[i], c[i-1], in[i-1] and fixes x[i-1]; blocks of BL steps, the next block's inputs fetched ahead.
+    double yprev = xk_[0] * scl;
+    {
+      const long long nsteps = n - 1;                                // steps i = 1 .. n-1
+      auto fetch = [&](double (&r)[3][BL / 64], long long i0) __attribute__((always_inline)) {       // step index i0 + u -> i = i0 + u + 1
 #pragma unroll
-      for (int u = 0; u < DB; ++u) {
-        const long long i = i0 + u;
-        const bool ok = i < n;
-        xv[u] = ok ? x[at(i)] : 0.0;
-        cv[u] = ok ? c[at(i - 1)] : 0.0;
-        fv[u] = ok ? in[at(i - 1)] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < DB; ++u) {
-        const long long i = i0 + u;
-        if (i < n) {
-          double yi = xv[u] * scl;
-          if (fv[u] == 0) {
-            yi -= cv[u] * yprev;
-            x[at(i - 1)] = yprev;
-          } else {
-            const double temp = yprev;
-            x[at(i - 1)] = yi;
-            yi = temp - cv[u] * yi;
-          }
-          yprev = yi;
+        for (int q = 0; q < BL / 64; ++q) {
+          const long long i = i0 + l + 64 * q + 1;
+          const bool ok = i < n;
+          r[0][q] = ok ? xk_[i] : 0.0;
+          r[1][q] = ok ? ck_[i - 1] : 0.0;
+          r[2][q] = ok ? (double)ik_[i - 1] : 0.0;
         }
+      };
+      auto stash = [&](int bufi, const double (&r)[3][BL / 64]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < BL / 64; ++q) {
+          s_in[bufi][0][l + 64 * q] = r[0][q];
+          s_in[bufi][1][l + 64 * q] = r[1][q];
+          s_in[bufi][2][l + 64 * q] = r[2][q];
+        }
+      };
+      double r[3][BL / 64];
+      fetch(r, 0);
+      stash(0, r);
+      wsync();
+      int bufi = 0;
+      for (long long i0 = 0; i0 < nsteps; i0 += BL, bufi ^= 1) {
+        const int cnt = (int)((nsteps - i0 < BL) ? (nsteps - i0) : BL);
+        const bool more = i0 + BL < nsteps;
+        if (more) fetch(r, i0 + BL);                                 // in flight behind this block's recurrence
+        for (int u0 = 0; u0 < cnt; u0 += DB) {
+          double xv[DB], cv[DB], fv[DB];
+#pragma unroll
+          for (int u = 0; u < DB; ++u) {
+            const int uu = (u0 + u < BL) ? u0 + u : BL - 1;
+            xv[u] = s_in[bufi][0][uu]; cv[u] = s_in[bufi][1][uu]; fv[u] = s_in[bufi][2][uu];
+          }
+#pragma unroll
+          for (int u = 0; u < DB; ++u) {
+            if (u0 + u < cnt) {
+              double yi = xv[u] * scl;
+              double outv;
+              if (fv[u] == 0.0) {
+                yi -= cv[u] * yprev;
+                outv = yprev;
+              } else {
+                const double temp = yprev;
+                outv = yi;
+                yi = temp - cv[u] * yi;
+              }
+              if (l == 0) s_out[0][u0 + u] = outv;                   // x[i - 1]
+              yprev = yi;
+            }
+          }
+        }
+        if (more) stash(bufi ^ 1, r);
+        wsync();
+        for (int u = l; u < cnt; u += 64) xk_[i0 + u] = s_out[0][u];  // x[i-1], i = i0 + u + 1
+        wsync();
       }
+      if (l == 0) xk_[n - 1] = yprev;
     }
-    x[at(n - 1)] = yprev;
-    // back substitution, tiny pivots replaced by +-tol (doubled until the quotient is representable)
+    __threadfence_block();
+    wsync();
+    // ---- back substitution, tiny pivots replaced by +-tol (doubled until the quotient is representable); i = n-1 .. 0
     double y1 = 0.0, y2 = 0.0;                                      // x[i+1], x[i+2]
     xmax = 0.0;
-    for (long long i0 = n - 1; i0 >= 0; i0 -= DB) {
-      double xv[DB], av[DB], bv[DB], dv[DB];
+    {
+      auto fetch = [&](double (&r)[4][BL / 64], long long ib) __attribute__((always_inline)) {       // block = i in (ib - BL, ib], u = ib - i
 #pragma unroll
-      for (int u = 0; u < DB; ++u) {
-        const long long i = i0 - u;
-        const bool ok = i >= 0;
-        xv[u] = ok ? x[at(i)] : 0.0;
-        av[u] = ok ? a[at(i)] : 1.0;
-        bv[u] = (ok && i + 1 < n) ? b[at(i)] : 0.0;
-        dv[u] = (ok && i + 2 < n) ? dd[at(i)] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < DB; ++u) {
-        const long long i = i0 - u;
-        if (i >= 0) {
-          const double temp = xv[u] - bv[u] * y1 - dv[u] * y2;
-          double ak = av[u];
-          double pert = copysign(tol, ak);
-          while (fabs(ak) < 1.0 && (fabs(ak) < 1e-300 ? true : fabs(temp) > fabs(ak) * 1e300)) {
-            ak += pert;
-            pert *= 2.0;
-          }
-          const double xi = temp / ak;
-          x[at(i)] = xi;
-          xmax = fmax(xmax, fabs(xi));
-          y2 = y1;
-          y1 = xi;
+        for (int q = 0; q < BL / 64; ++q) {
+          const long long i = ib - (l + 64 * q);
+          const bool ok = i >= 0;
+          r[0][q] = ok ? xk_[i] : 0.0;
+          r[1][q] = ok ? ak_[i] : 1.0;
+          r[2][q] = (ok && i + 1 < n) ? bk_[i] : 0.0;
+          r[3][q] = (ok && i + 2 < n) ? dk_[i] : 0.0;
         }
+      };
+      auto stash = [&](int bufi, const double (&r)[4][BL / 64]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < BL / 64; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s_in[bufi][j][l + 64 * q] = r[j][q];
+      };
+      double r[4][BL / 64];
+      fetch(r, n - 1);
+      stash(0, r);
+      wsync();
+      int bufi = 0;
+      for (long long ib = n - 1; ib >= 0; ib -= BL, bufi ^= 1) {
+        const int cnt = (int)((ib + 1 < BL) ? (ib + 1) : BL);
+        const bool more = ib - BL >= 0;
+        if (more) fetch(r, ib - BL);
+        for (int u0 = 0; u0 < cnt; u0 += DB) {
+          double xv[DB], av[DB], bv[DB], dv[DB];
+#pragma unroll
+          for (int u = 0; u < DB; ++u) {
+            const int uu = (u0 + u < BL) ? u0 + u : BL - 1;
+            xv[u] = s_in[bufi][0][uu]; av[u] = s_in[bufi][1][uu]; bv[u] = s_in[bufi][2][uu]; dv[u] = s_in[bufi][3][uu];
+          }
+#pragma unroll
+          for (int u = 0; u < DB; ++u) {
+            if (u0 + u < cnt) {
+              const double temp = xv[u] - bv[u] * y1 - dv[u] * y2;
+              double ak = av[u];
+              double pert = copysign(tol, ak);
+              while (fabs(ak) < 1.0 && (fabs(ak) < 1e-300 ? true : fabs(temp) > fabs(ak) * 1e300)) {
+                ak += pert;
+                pert *= 2.0;
+              }
+              const double xi = temp / ak;
+              if (l == 0) s_out[0][u0 + u] = xi;
+              xmax = fmax(xmax, fabs(xi));
+              y2 = y1;
+              y1 = xi;
+            }
+          }
+        }
+        if (more) stash(bufi ^ 1, r);
+        wsync();
+        for (int u = l; u < cnt; u += 64) xk_[ib - u] = s_out[0][u];
+        wsync();
       }
     }
+    __threadfence_block();
+    wsync();
   }
 }
 
@@ -218,12 +332,13 @@ __global__ void __launch_bounds__(64) dpss_invit_kernel(DpssMat T, int K, int KP
 // first Mout points of each in `tapers` (sym=False: the periodic window is the symmetric one of M + 1 points cut short)
 __global__ void __launch_bounds__(256) dpss_finish_kernel(const double* x, long long M, int KP, long long Mout, double* full,
                                                           double* tapers) {
+  (void)KP;                                // (x is [k][M] since the wave-per-vector inverse iteration)
   __shared__ double part[256];
   __shared__ long long firsts[256];
   const int k = blockIdx.x;
   double ss = 0.0;
   for (long long i = threadIdx.x; i < M; i += 256) {
-    const double v = x[(size_t)i * KP + k];
+    const double v = x[(size_t)k * M + i];
     ss += v * v;
   }
   part[threadIdx.x] = ss;
@@ -237,7 +352,7 @@ __global__ void __launch_bounds__(256) dpss_finish_kernel(const double* x, long 
   double sign = 1.0;
   if ((k & 1) == 0) {                      // symmetric tapers: positive average
     double sm = 0.0;
-    for (long long i = threadIdx.x; i < M; i += 256) sm += x[(size_t)i * KP + k];
+    for (long long i = threadIdx.x; i < M; i += 256) sm += x[(size_t)k * M + i];
     part[threadIdx.x] = sm;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -249,7 +364,7 @@ __global__ void __launch_bounds__(256) dpss_finish_kernel(const double* x, long 
     const double thresh = fmax(1e-7, 1.0 / (double)M);
     long long first = M;
     for (long long i = threadIdx.x; i < M; i += 256) {
-      const double v = x[(size_t)i * KP + k] * inv;
+      const double v = x[(size_t)k * M + i] * inv;
       if (v * v > thresh) {
         first = i;
         break;
@@ -262,11 +377,11 @@ __global__ void __launch_bounds__(256) dpss_finish_kernel(const double* x, long 
       __syncthreads();
     }
     const long long f0 = firsts[0];
-    if (f0 < M && x[(size_t)f0 * KP + k] < 0.0) sign = -1.0;
+    if (f0 < M && x[(size_t)k * M + f0] < 0.0) sign = -1.0;
   }
   const double scale = sign * inv;
   for (long long i = threadIdx.x; i < M; i += 256) {
-    const double v = x[(size_t)i * KP + k] * scale;
+    const double v = x[(size_t)k * M + i] * scale;
     full[(size_t)k * M + i] = v;
     if (i < Mout) tapers[(size_t)k * Mout + i] = v;
   }
@@ -365,8 +480,7 @@ int launch_dpss(long long M_out, double NW, int K, int sym, double* tapers, doub
   double* dd = reinterpret_cast<double*>(base + o);   o += arr;
   unsigned char* in = reinterpret_cast<unsigned char*>(base + o);
   hipLaunchKernelGGL(dpss_bisect_kernel, dim3(K), dim3(64), 0, st, T, K, glo, ghi, pivmin, lam);
-  hipLaunchKernelGGL(dpss_invit_kernel, dim3((unsigned)(KP / 64)), dim3(64), 0, st, T, K, (int)KP, lam, onenrm, eps, a, b, c, dd,
-                     in, x);
+  hipLaunchKernelGGL(dpss_invit_kernel, dim3((unsigned)K), dim3(64), 0, st, T, K, lam, onenrm, eps, a, b, c, dd, in, x);
   double* full = a;                          // the factors are dead once x is final
   hipLaunchKernelGGL(dpss_finish_kernel, dim3(K), dim3(256), 0, st, x, M, (int)KP, M_out, full, tapers);
   if (ratios) {
