@@ -8,8 +8,8 @@
 // On the host that costs 55 s for a 220-s segment at 500 Hz (M = 110 000, 438 tapers) against 76 ms for the whole
 // PSD on the GPU.  The same algorithm here, restated for the device (PARITY UNPINNED like the rest of the PSD leg:
 // checked against SciPy's own dpss in tests/test_psd.py, ~1e-10):
-//   dpss_bisect_kernel   the Kmax largest eigenvalues by Sturm counts, one wave per eigenvalue, 64-way multisection
-//                        (11 rounds of 64 probes instead of ~55 bisection steps); d_i and e_i come from their closed
+//   dpss_bisect_kernel   the Kmax largest eigenvalues by Sturm counts, 256 probes per eigenvalue and round (7 rounds of
+//                        257-way multisection instead of ~55 bisection steps); d_i and e_i come from their closed
 //                        forms, nothing is read from memory;
 //   dpss_invit_kernel    eigenvectors by inverse iteration, one THREAD per eigenvector (a tridiagonal LU with partial
 //                        pivoting and its solves are first-order recurrences: nothing to parallelise inside one vector,
@@ -66,21 +66,29 @@ __device__ __forceinline__ long long sturm_count(const DpssMat& T, double x, dou
   return c;
 }
 
-// one wave per eigenvalue: k-th largest, k = blockIdx.x
-__global__ void __launch_bounds__(64) dpss_bisect_kernel(DpssMat T, int K, double glo, double ghi, double pivmin, double* lam) {
-  const int k = blockIdx.x, t = threadIdx.x;
+// one workgroup of 256 probes per eigenvalue: k-th largest, k = blockIdx.x.  257-way multisection until the bracket is
+// below the spacing of doubles at the eigenvalue (seven rounds at 110 000 points: the Gershgorin interval is ~6e9 wide and
+// the wanted eigenvalues ~3e9, so anything past a 2e16-fold reduction is below an ulp -- the 64-probe version ran eleven
+// rounds, the last two inside one ulp).  Four waves per eigenvalue are free: 440 eigenvalues leave most SIMDs idle.
+__global__ void __launch_bounds__(256) dpss_bisect_kernel(DpssMat T, int K, double glo, double ghi, double pivmin, double* lam) {
+  __shared__ int s_first[4];
+  const int k = blockIdx.x, t = threadIdx.x, w = t >> 6;
   if (k >= K) return;
   const long long idx = T.M - 1 - k;               // ascending index of the eigenvalue
   double lo = glo, hi = ghi;                       // count(lo) <= idx < count(hi)
-  for (int round = 0; round < 11; ++round) {
-    const double step = (hi - lo) / 65.0;
+  for (int round = 0; round < 12; ++round) {
+    if (hi - lo <= 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi))) break;      // workgroup-uniform
+    const double step = (hi - lo) / 257.0;
     const double x = lo + step * (double)(t + 1);
     const long long c = sturm_count(T, x, pivmin);
     const unsigned long long above = __builtin_amdgcn_ballot_w64(c >= idx + 1);
-    if (above == 0ull) {
-      lo = lo + step * 64.0;
+    if ((t & 63) == 0) s_first[w] = above ? 64 * w + (int)__builtin_ctzll(above) : 256;
+    __syncthreads();
+    const int ts = min(min(s_first[0], s_first[1]), min(s_first[2], s_first[3]));   // first probe with count > idx
+    __syncthreads();
+    if (ts == 256) {
+      lo = lo + step * 256.0;
     } else {
-      const int ts = (int)__builtin_ctzll(above);
       hi = lo + step * (double)(ts + 1);
       lo = lo + step * (double)ts;
     }
@@ -479,7 +487,7 @@ int launch_dpss(long long M_out, double NW, int K, int sym, double* tapers, doub
   double* c = reinterpret_cast<double*>(base + o);    o += arr;
   double* dd = reinterpret_cast<double*>(base + o);   o += arr;
   unsigned char* in = reinterpret_cast<unsigned char*>(base + o);
-  hipLaunchKernelGGL(dpss_bisect_kernel, dim3(K), dim3(64), 0, st, T, K, glo, ghi, pivmin, lam);
+  hipLaunchKernelGGL(dpss_bisect_kernel, dim3(K), dim3(256), 0, st, T, K, glo, ghi, pivmin, lam);
   hipLaunchKernelGGL(dpss_invit_kernel, dim3((unsigned)K), dim3(64), 0, st, T, K, lam, onenrm, eps, a, b, c, dd, in, x);
   double* full = a;                          // the factors are dead once x is final
   hipLaunchKernelGGL(dpss_finish_kernel, dim3(K), dim3(256), 0, st, x, M, (int)KP, M_out, full, tapers);

@@ -4,7 +4,8 @@ PARITY UNPINNED: the reference delegates to mne==1.11.0 (`psd_array_multitaper`)
 offline; the kernel path restates that algorithm with mne's defaults (see include/hypermvar.h,
 `hmv_psd_multitaper_f64`, and oracle/psd_oracle.py).  The DPSS tapers come from the device too (`hmv_dpss_f64`: the
 algorithm of scipy.signal.windows.dpss, which mne calls, restated for the GPU) and are cached per (n_times,
-time-half-bandwidth) in memory and on disk; everything per sample runs on the device:
+time-half-bandwidth) in memory (on disk too when $HYPERMVAR_DPSS_CACHE names a directory); everything per sample runs on
+the device:
 taper products, batched real-to-complex FFTs (hipFFT) and the eigenvalue-weighted power sum.
 """
 from __future__ import annotations
@@ -22,11 +23,10 @@ __all__ = ["compute_psd_multitaper", "compute_psd_multitaper_device", "average_p
 
 
 def _taper_cache_dir():
-    """Where DPSS tapers are kept between processes: $HYPERMVAR_DPSS_CACHE, default <tmp>/hypermvar_dpss ('' = off)."""
-    d = os.environ.get("HYPERMVAR_DPSS_CACHE")
-    if d == "":
-        return None
-    return d or os.path.join(tempfile.gettempdir(), "hypermvar_dpss")
+    """Where DPSS tapers are kept between processes: $HYPERMVAR_DPSS_CACHE (unset or '' = no disk cache).  Opt-in since
+    the tapers of a length come off the GPU in ~0.15 s: reading 390 MB (439 tapers x 110 000 points) back from disk is
+    not faster, and a batch of real recordings -- every segment a length of its own -- would write that much per segment."""
+    return os.environ.get("HYPERMVAR_DPSS_CACHE") or None
 
 
 def dpss_device(n_times: int, half_nbw: float, k_max: int, sym: bool = False, engine=None):

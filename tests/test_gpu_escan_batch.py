@@ -122,12 +122,23 @@ def _write_full(path, seed, fs, dur_s, events, n_eeg=32):
         np.savez(f, data=x, time=t, channels=np.asarray(chans), attrs=json.dumps(attrs), events=json.dumps(ev))
 
 
-def make_config5_tree(root, dyads, fs=500.0):
-    """SECORE (one 220 s event, /root/reference/src/secore_loader.py:117), passive movies (three films) and a free talk"""
-    tasks = {"secore": (230.0, [("secore", 1.0, 220.0)]),
-             "passive_movies": (215.0, [("Peppa", 1.0, 60.0), ("Incredibles", 70.0, 60.0), ("Brave", 140.0, 60.0)]),
-             "talk": (190.0, [("talk_1", 1.0, 180.0)])}
+def make_config5_tree(root, dyads, fs=500.0, jitter=False):
+    """SECORE (one 220 s event, /root/reference/src/secore_loader.py:117), passive movies (three films) and a free talk.
+    jitter: every dyad's events last a different number of samples (up to 0.9 s more: the same window counts), as real
+    event durations do -- every segment then has a length nobody met before (DPSS tapers, FFT plans, chirp-z tables)."""
+    base = {"secore": (230.0, [("secore", 1.0, 220.0)]),
+            "passive_movies": (215.0, [("Peppa", 1.0, 60.0), ("Incredibles", 70.0, 60.0), ("Brave", 140.0, 60.0)]),
+            "talk": (190.0, [("talk_1", 1.0, 180.0)])}
     for d, dy in enumerate(dyads):
+        tasks = base
+        if jitter:
+            tasks, e = {}, 0
+            for task, (dur, evs) in base.items():
+                out = []
+                for name, start, length in evs:
+                    out.append((name, start, length + ((37 * d + 113 * e) % 450) / fs))
+                    e += 1
+                tasks[task] = (dur, out)
         for r, (code, role) in enumerate((("ch", "child"), ("cg", "caregiver"))):
             for k, (task, (dur, ev)) in enumerate(tasks.items()):
                 _write_full(Path(root) / "EEG" / dy / role / f"{dy}_EEG_{code}_{task}.nc", 1000 * d + 10 * k + r, fs, dur, ev)
