@@ -526,7 +526,9 @@ def test_pipelined_levinson_whittle_form_equals_the_first_form(m, n, p, nw):
     (33, 300, 2, 64, 200, 8, [(0, 64), (10, 11)]),
     (19, 400, 3, 32, 150, 8, [(1, 31), (0, 2), (31, 32)]),
     (4, 160, 5, 640, 300, 8, [(0, 640), (100, 101), (320, 640)]),     # 16 padded channels: ONE band's weights per pass
-    (48, 600, 4, 96, 200, 8, [(0, 96), (95, 96), (40, 41), (0, 0), (1, 2), (3, 96)])])
+    (48, 600, 4, 96, 200, 8, [(0, 96), (95, 96), (40, 41), (0, 0), (1, 2), (3, 96)]),
+    (2, 200, 3, 32, 3, 8, [(0, 32)]),                                 # fewer windows than the lag: every row behind K3
+    (64, 1000, 8, 64, 1, 8, [(k, k + 5) for k in range(0, 60, 5)])])  # one window, twelve bands (three passes)
 def test_band_sums_inside_k3_equal_band_sums_of_the_full_array(m, n, p, F, nw, lag, bins):
     """The reduced product (`sliding_ffdtf(bands=...)`, hmv_sliding_ffdtf_bands_f64): K3's row workers add the frequency
     bands up from the published |H|^2 rows and the (items, m, m, F) array is never written -- the same BITS as
