@@ -130,13 +130,20 @@ __global__ void __launch_bounds__(64) dpss_invit_kernel(DpssMat T, int K, const 
     double ak = T.d(0) - lambda;                                   // a[i] of the running elimination
     double bk = n > 1 ? T.e(0) : 0.0;                              // b[i] (superdiagonal), may be rewritten by an interchange
     double scale1 = fabs(ak) + fabs(bk);
+    // d_i and e_i from running values instead of 64-bit integer conversions per step (h -= 1, i + 1 += 1, M - 1 - i -= 1:
+    // half-integers and integers below 2^53, exact, so the same numbers as T.d / T.e)
+    double hn = 0.5 * (double)(n - 1) - 1.0;                       // (M - 1 - 2 (i + 1)) / 2 at i = 0
+    double f1 = 1.0, g1 = (double)(n - 1);                         // i + 1, M - 1 - i
     for (long long i0 = 0; i0 + 1 < n; i0 += BL) {
       const int cnt = (int)((n - 1 - i0 < BL) ? (n - 1 - i0) : BL);
       for (int u = 0; u < cnt; ++u) {
         const long long i = i0 + u;
-        const double ci = T.e(i);                                    // subdiagonal c[i]
-        double a1 = T.d(i + 1) - lambda;                             // a[i+1]
-        double b1 = (i + 2 < n) ? T.e(i + 1) : 0.0;                  // b[i+1]
+        const double ci = 0.5 * f1 * g1;                             // subdiagonal c[i] = e(i)
+        double a1 = hn * hn * T.c2w - lambda;                        // a[i+1] = d(i+1) - lambda
+        f1 += 1.0;
+        g1 -= 1.0;
+        hn -= 1.0;
+        double b1 = (i + 2 < n) ? 0.5 * f1 * g1 : 0.0;               // b[i+1] = e(i+1)
         const double scale2 = fabs(ci) + fabs(a1) + ((i + 2 < n) ? fabs(b1) : 0.0);
         double astore = ak, bstore = bk, cstore = 0.0, dstore = 0.0;
         double flag = 0.0;
