@@ -402,7 +402,7 @@ class Engine:
             if nb == 0 or not self.bands_in_kernel(m, F) or (flags & _lib.FLAG_UNFUSED_NORM):
                 # two calls: the full array (scratch), then its band sums
                 res = self.sliding_ffdtf(x, item_rec, item_start, n, p, f, fs, return_ar=return_ar, check=check, chunk=chunk,
-                                         k3_events=k3_events, overlap=overlap, flags=flags, grid=grid, validate=False)
+                                         k3_events=k3_events, overlap=overlap, flags=flags, grid=grid, validate=validate)
                 full = res[0] if isinstance(res, tuple) else res
                 red = self.band_sums(full, bands[0], bands[1])
                 if out is not None:
