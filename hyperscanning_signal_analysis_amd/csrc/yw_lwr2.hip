@@ -221,12 +221,6 @@ __global__ void __launch_bounds__(256, 3) yw_lwr2_kernel(YwArgs a) {
 #pragma unroll
       for (int J = 0; J < NJ; ++J) v[ii][J] = 0.0;
   };
-  auto copy = [&](double (&d)[NIW][NJ], const double (&s)[NIW][NJ]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ii = 0; ii < NIW; ++ii)
-#pragma unroll
-      for (int J = 0; J < NJ; ++J) d[ii][J] = s[ii][J];
-  };
   // Tile stores are asm statements the compiler does not count.  On gfx9-family targets loads and stores share ONE
   // counter (vmcnt) and may retire out of order with respect to each other, so with a store in flight hipcc turns every
   // wait for a load into s_waitcnt vmcnt(0) -- i.e. each product would wait for the prefetches issued just before it
