@@ -38,3 +38,16 @@ for prio in (0, -1):
         torch.cuda.synchronize()
         print("prio %2d: K3 done at %.3f ms, K1+K2 done at %.3f ms" % (prio, t0.elapsed_time(a1), t0.elapsed_time(b1)))
         del oa, ob
+    # the other order: K1 + K2 of the NEXT recording queued first, K3 of the current one behind it on the other stream
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); a1 = torch.cuda.Event(enable_timing=True); b1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        sA.wait_stream(torch.cuda.current_stream()); sB.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sB):
+            ob = k12(); b1.record()
+        with torch.cuda.stream(sA):
+            oa = k3(); a1.record()
+        torch.cuda.synchronize()
+        print("prio %2d, K1+K2 first: K3 done at %.3f ms, K1+K2 done at %.3f ms" % (prio, t0.elapsed_time(a1), t0.elapsed_time(b1)))
+        del oa, ob
